@@ -1,0 +1,54 @@
+"""Own ResNet-50 (v1.5: stride on the 3x3, bias-free convs, BN eps 1e-5) with torchvision's
+attribute names, so the reference KeyEncoder (modules.py:127-149) can be constructed without
+torchvision installed.  Only used by oracle/gen_golden.py in the build container."""
+import torch.nn as nn
+
+
+class ResNet50_Weights:
+    DEFAULT = None
+
+
+class Bottleneck(nn.Module):
+    def __init__(self, cin, planes, stride=1, project=False):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = None
+        if project:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, planes * 4, 1, stride, bias=False),
+                                            nn.BatchNorm2d(planes * 4))
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        y = self.relu(self.bn1(self.conv1(x)))
+        y = self.relu(self.bn2(self.conv2(y)))
+        y = self.bn3(self.conv3(y))
+        return self.relu(y + idt)
+
+
+def _stage(cin, planes, n, stride):
+    mods = [Bottleneck(cin, planes, stride, True)]
+    mods += [Bottleneck(planes * 4, planes) for _ in range(n - 1)]
+    return nn.Sequential(*mods)
+
+
+class _R50(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        self.layer1 = _stage(64, 64, 3, 1)
+        self.layer2 = _stage(256, 128, 4, 2)
+        self.layer3 = _stage(512, 256, 6, 2)
+        self.layer4 = _stage(1024, 512, 3, 2)
+
+
+def resnet50(weights=None, **kw):
+    return _R50()

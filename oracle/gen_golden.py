@@ -1,0 +1,215 @@
+"""Capture golden vectors from the REAL reference (build container only) -> tests/golden/*.npz.
+
+Imports ``/root/reference`` with two shims: a stub ``torchvision`` package
+(``oracle/_stub``) and a no-op ``model_zoo.load_url``.  The reference never travels to the GPU box;
+only the arrays written here do.  Inputs are not stored: they are regenerated bit-identically from
+``eva_vos_amd.synth`` (NumPy Philox streams).
+
+Run:  python oracle/gen_golden.py            (writes fixtures, prints oracle-vs-reference deltas)
+"""
+from __future__ import annotations
+
+import contextlib
+import io
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "oracle", "_stub"), "/root/reference", ROOT]
+torch.set_grad_enabled(False)
+
+import mivos.model.propagation.mod_resnet as _mr  # noqa: E402  (reference)
+
+_mr.model_zoo.load_url = lambda *a, **k: {}
+with contextlib.redirect_stdout(io.StringIO()):
+    from mivos.inference_core import InferenceCore as RefCore  # noqa: E402
+    from mivos.model.fusion_net import FusionNet as RefFus  # noqa: E402
+    from mivos.model.propagation.prop_net import PropagationNetwork as RefNet  # noqa: E402
+    from mivos.model.aggregate import aggregate_wbg  # noqa: E402
+    from mivos.tensor_util import pad_divide_by  # noqa: E402
+
+from eva_vos_amd import synth  # noqa: E402
+from eva_vos_amd.params import FusionNet, PropagationNetwork  # noqa: E402
+from oracle import stcn_oracle as O  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def load_reference(seed=0):
+    with contextlib.redirect_stdout(io.StringIO()):
+        net, fus = RefNet().eval(), RefFus().eval()
+    psd = synth.recipe_state_dict(PropagationNetwork(), seed)
+    fsd = synth.recipe_state_dict(FusionNet(), seed)
+    net.load_state_dict(psd, strict=True)
+    fus.load_state_dict(fsd, strict=True)
+    return net, fus, psd, fsd
+
+
+def summarize(t: torch.Tensor, stride=1):
+    """Compact fingerprint of a tensor: strided samples + moments."""
+    a = t.detach().float().cpu().numpy()
+    flat = a.reshape(-1)
+    return dict(shape=np.array(a.shape), sample=flat[::stride].copy(),
+                moments=np.array([flat.sum(dtype=np.float64), np.abs(flat).sum(dtype=np.float64),
+                                  (flat.astype(np.float64) ** 2).sum()]))
+
+
+def put(dst, name, t, stride=1):
+    for k, v in summarize(t, stride).items():
+        dst[f"{name}.{k}"] = v
+
+
+def dmax(a, b):
+    return float((a - b).abs().max())
+
+
+# ------------------------------------------------------------------------------------------
+def stage_case(tag, H, W, k, net, psd, out):
+    """One frame pair through every stage; store reference outputs; report oracle deltas."""
+    T = 3
+    img = synth.synthetic_clip(T, H, W)
+    msk = synth.synthetic_mask(T, H, W, k)
+    imgs, pad = pad_divide_by(img, 16)
+    m0, _ = pad_divide_by(msk[:, 0], 16)
+    m1, _ = pad_divide_by(msk[:, 1], 16)
+    fw = O.fold_bn(psd)
+    rep = {}
+
+    kf0 = net.encode_key(imgs[:, 0])
+    kf1 = net.encode_key(imgs[:, 1])
+    kf2 = net.encode_key(imgs[:, 2])
+    okf0 = O.encode_key(fw, imgs[:, 0])
+    names = ["k16", "f16_thin", "f16", "f8", "f4"]
+    for n, r, o in zip(names, kf0, okf0):
+        put(out, f"{tag}.key0.{n}", r, stride=1 if n == "k16" else 37)
+        rep[f"key.{n}"] = dmax(r, o) / float(r.abs().max())
+
+    v0 = net.encode_value(imgs[:, 0], kf0[2], m0)                 # [k,512,1,h,w]
+    v1 = net.encode_value(imgs[:, 1], kf1[2], m1)
+    ov0 = O.encode_value(fw, imgs[:, 0], okf0[2], m0)
+    put(out, f"{tag}.value0", v0[:, :, 0], stride=11)
+    rep["value"] = dmax(v0[:, :, 0], ov0) / float(v0.abs().max())
+
+    # memory bank of two frames, query = frame 2
+    mk = torch.stack([kf0[0], kf1[0]], 2)                         # [1,64,2,h,w]
+    mv = torch.cat([v0, v1], 2)                                   # [k,512,2,h,w]
+    aff = net.memory.get_affinity(mk, kf2[0])                     # [1,THW,HW] dense
+    ro = torch.cat([net.memory.readout(aff, mv[i:i + 1]) for i in range(k)], 0)
+    rows = lambda x: x.flatten(2).transpose(1, 2).contiguous()    # noqa: E731
+    mk_rows = torch.cat([rows(kf0[0])[0], rows(kf1[0])[0]], 0)
+    mv_rows = torch.cat([rows(v0[:, :, 0]), rows(v1[:, :, 0])], 1)
+    oidx, ow, oro = O.memory_read(mk_rows, mv_rows, rows(kf2[0])[0])
+    A = aff[0]                                                    # [N,Q]
+    ref_w, ref_idx = torch.topk(A, O.TOP_K, dim=0)
+    out[f"{tag}.read.topk_idx"] = ref_idx.t().numpy().astype(np.int32)
+    out[f"{tag}.read.topk_w"] = ref_w.t().numpy().astype(np.float32)
+    put(out, f"{tag}.read.readout", ro, stride=7)
+    h, w = kf2[0].shape[-2:]
+    oro_img = oro.transpose(1, 2).reshape(k, 512, h, w)
+    rep["readout"] = dmax(ro, oro_img) / float(ro.abs().max())
+    rep["topk_w"] = dmax(torch.gather(A, 0, oidx.t()).t(), ow)
+
+    qv = kf2[1].expand(k, -1, -1, -1)
+    logits = net.decoder(torch.cat([ro, qv], 1), kf2[3], kf2[4])
+    prob = torch.sigmoid(logits)
+    okf2 = O.encode_key(fw, imgs[:, 2])
+    oprob, _ = O.decode(fw, oro_img, okf2[1], okf2[3], okf2[4])
+    put(out, f"{tag}.decode.logit", logits, stride=13)
+    put(out, f"{tag}.decode.prob", prob, stride=13)
+    rep["decode.prob"] = dmax(prob, oprob)
+    agg = aggregate_wbg(prob, keep_bg=True)
+    put(out, f"{tag}.aggregate", agg, stride=13)
+    rep["aggregate"] = dmax(agg, O.aggregate(oprob))
+
+    # attention read + fusion net (fusion inputs: prev = agg of a shifted prob)
+    pos = (m0 - 0.3).clamp(0, 1)
+    neg = (0.3 - m0).clamp(0, 1)
+    bgc = torch.ones_like(pos[:1]) * 0.1                          # bg row (k+1 rows in total)
+    pos = torch.cat([bgc, pos], 0)
+    neg = torch.cat([bgc * 2, neg], 0)
+    attn = net.get_attention(kf0[0].unsqueeze(2), pos, neg, kf2[0])
+    oattn = O.attention_read(rows(kf0[0])[0], rows(kf2[0])[0], pos, neg)
+    put(out, f"{tag}.attention", attn, stride=13)
+    rep["attention"] = dmax(attn, oattn)
+    out[f"{tag}.pad"] = np.array(pad)
+    return rep
+
+
+def fusion_case(tag, H, W, fus, fsd, out):
+    img = synth.synthetic_clip(2, H, W)
+    imgs, _ = pad_divide_by(img, 16)
+    g = np.random.Generator(np.random.Philox(key=[7, 7]))
+    nh, nw = imgs.shape[-2:]
+    prev = torch.from_numpy(g.uniform(0, 1, (1, 1, nh, nw)).astype(np.float32))
+    curr = torch.from_numpy(g.uniform(0, 1, (1, 1, nh, nw)).astype(np.float32))
+    attn = torch.from_numpy(g.uniform(0, 0.2, (1, 2, nh, nw)).astype(np.float32))
+    ref = fus(imgs[:, 1], prev, curr, attn, torch.tensor([[0.25, 0.75]]))
+    o = O.fusion_net(O.fold_bn(fsd), imgs[:, 1], prev, curr, attn, 0.25, 0.75)
+    put(out, f"{tag}.fusion_logit", ref, stride=13)
+    return {"fusion": dmax(ref, o)}
+
+
+def seq_case(tag, H, W, k, T, mem_freq, script, net, fus, psd, fsd, out):
+    """script: list of (frame_idx_for_mask, idx) interactions."""
+    img = synth.synthetic_clip(T, H, W)
+    msk = synth.synthetic_mask(T, H, W, k)
+    scribble = k > 1
+    ref = RefCore(net, fus, img, k, mem_freq=mem_freq, device="cpu")
+    orc = O.OracleCore(psd, fsd, img, k, mem_freq=mem_freq)
+    rep = {}
+    for r, (mf, idx) in enumerate(script):
+        m = msk[:, mf]
+        if scribble:
+            m = torch.cat([1 - m.sum(0, keepdim=True).clamp(0, 1), m], 0)
+        rm = ref.interact(m.clone(), idx, scribble=scribble)
+        om = orc.interact(m.clone(), idx, scribble=scribble)
+        out[f"{tag}.r{r}.masks"] = np.packbits(rm.astype(bool), axis=None) if k == 1 else rm
+        out[f"{tag}.r{r}.prob_h"] = ref.prob[:, :, 0, ::2, ::2].numpy().astype(np.float16)
+        put(out, f"{tag}.r{r}.prob", ref.prob, stride=97)
+        rep[f"r{r}.prob"] = dmax(ref.prob, orc.prob)
+        rep[f"r{r}.mask_mismatch"] = int((rm != om).sum())
+    out[f"{tag}.trace"] = np.array([[t["idx"], int(t["forward"]), t["frames"], t["bank"], int(t["fuse"])]
+                                     for t in orc.trace])
+    out[f"{tag}.shape"] = np.array([T, H, W, k, mem_freq])
+    out[f"{tag}.script"] = np.array(script)
+    return rep
+
+
+SEQ_CASES = {
+    "seqA": dict(H=128, W=160, k=1, T=12, mem_freq=5, script=[(0, 0), (8, 8), (7, 8)]),
+    "seqB": dict(H=100, W=150, k=1, T=8, mem_freq=3, script=[(3, 3), (6, 6)]),
+    "seqC": dict(H=128, W=160, k=3, T=8, mem_freq=2, script=[(0, 0), (5, 5)]),
+}
+STAGE_CASES = {
+    "stA": dict(H=128, W=160, k=1),
+    "stB": dict(H=100, W=150, k=3),
+}
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    net, fus, psd, fsd = load_reference()
+    for tag, c in STAGE_CASES.items():
+        out = {}
+        rep = stage_case(tag, c["H"], c["W"], c["k"], net, psd, out)
+        rep.update(fusion_case(tag, c["H"], c["W"], fus, fsd, out))
+        np.savez_compressed(os.path.join(GOLD, f"{tag}.npz"), **out)
+        print(tag, {k: f"{v:.2e}" for k, v in rep.items()})
+    for tag, c in SEQ_CASES.items():
+        out = {}
+        rep = seq_case(tag, net=net, fus=fus, psd=psd, fsd=fsd, out=out, **c)
+        np.savez_compressed(os.path.join(GOLD, f"{tag}.npz"), **out)
+        print(tag, rep)
+    if "--full" in sys.argv:          # one 480x854 frame: checksums only
+        out = {}
+        rep = stage_case("st480", 480, 854, 1, net, psd, out)
+        keep = {k: v for k, v in out.items() if k.endswith(".moments") or k.endswith(".shape") or "pad" in k}
+        np.savez_compressed(os.path.join(GOLD, "st480.npz"), **keep)
+        print("st480", {k: f"{v:.2e}" for k, v in rep.items()})
+
+
+if __name__ == "__main__":
+    main()

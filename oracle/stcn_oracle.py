@@ -1,0 +1,309 @@
+"""ORACLE (test infrastructure, never shipped, never measured as the product).
+
+CPU restatement (PyTorch fp32 on host cores) of the reference STCN/MiVOS mask-propagation path
+``mivos.inference_core.InferenceCore`` of thanosDelatolas/eva-vos.  Only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may import this file.
+
+Parity status: the reference ships no tests / golden vectors for this path, so
+this restatement is pinned against outputs of the reference itself, run in the build container by
+``oracle/gen_golden.py`` (fixtures under ``tests/golden/``; ``tests/test_oracle_golden.py``).
+
+The restatement is written from the algorithm, not from the reference source: BatchNorm is folded
+into the convolutions up front, the network is driven from a flat ``state_dict`` through a small
+functional interpreter, the memory read is the 50-sparse gather form (no dense [THW x HW] matrix is
+ever used for the read-out) and the memory bank is an explicit list of slots.
+
+Reference map (file:line under /root/reference):
+  fold / key encoder      mivos/model/propagation/modules.py:127-149 (+ torchvision Bottleneck v1.5)
+  key projection / comp   modules.py:166-175, prop_net.py:147,172-177
+  value encoder           modules.py:93-124, mod_resnet.py:49-78, prop_net.py:153-170
+  fuser / ResBlock / CBAM modules.py:15-52, cbam.py:21-77
+  memory read             prop_net.py:46-62 (top-k softmax), :80-106 (affinity), :108-115 (readout)
+  decoder                 prop_net.py:13-30,179-192, modules.py:152-163
+  aggregate               mivos/model/aggregate.py:22-37
+  attention read / fusion prop_net.py:117-138,198-211, fusion_net.py:32-50, inference_core.py:193-207
+  sequence logic          inference_core.py:34-99 (init), :126-191 (do_pass), :209-259 (interact)
+  padding                 mivos/tensor_util.py:62-80
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+TOP_K = 50          # prop_net.py:141
+BN_EPS = 1e-5
+
+
+# ----------------------------------------------------------------------------------------------
+# weights
+# ----------------------------------------------------------------------------------------------
+def fold_bn(sd: dict) -> dict:
+    """Return {conv_prefix: (weight, bias)} with every eval-mode BatchNorm folded into the
+    convolution in front of it (y = (x-mu)/sqrt(var+eps)*gamma+beta).  Linear layers too."""
+    sd = {k: v.detach().to(torch.float32).cpu() for k, v in sd.items() if v.is_floating_point()}
+    bn_of = {}
+    for name in sd:
+        if name.endswith(".running_mean"):
+            bn = name[: -len(".running_mean")]
+            # BN 'bnN' follows 'convN'; 'downsample.1' follows 'downsample.0'
+            head, leaf = bn.rsplit(".", 1)
+            conv = head + ".conv" + leaf[2:] if leaf.startswith("bn") else head + ".0"
+            bn_of[conv] = bn
+    out = {}
+    for name, w in sd.items():
+        if not name.endswith(".weight") or w.dim() < 2:
+            continue
+        pre = name[: -len(".weight")]
+        b = sd.get(pre + ".bias", torch.zeros(w.shape[0]))
+        if pre in bn_of:
+            bn = bn_of[pre]
+            s = sd[bn + ".weight"] / torch.sqrt(sd[bn + ".running_var"] + BN_EPS)
+            w = w * s.view(-1, *([1] * (w.dim() - 1)))
+            b = (b - sd[bn + ".running_mean"]) * s + sd[bn + ".bias"]
+        out[pre] = (w.contiguous(), b.contiguous())
+    return out
+
+
+def _conv(x, fw, name, stride=1, relu_in=False):
+    w, b = fw[name]
+    if relu_in:
+        x = F.relu(x)
+    return F.conv2d(x, w, b, stride=stride, padding=w.shape[-1] // 2)
+
+
+# ----------------------------------------------------------------------------------------------
+# network stages
+# ----------------------------------------------------------------------------------------------
+def _resblock(x, fw, pre):
+    r = _conv(x, fw, pre + ".conv1", relu_in=True)
+    r = _conv(r, fw, pre + ".conv2", relu_in=True)
+    skip = _conv(x, fw, pre + ".downsample") if (pre + ".downsample") in fw else x
+    return skip + r
+
+
+def encode_key(fw, img):
+    """img [1,3,H,W] (H,W multiples of 16) -> k16, f16_thin, f16, f8, f4."""
+    x = F.relu(_conv(img, fw, "key_encoder.conv1", stride=2))
+    x = F.max_pool2d(x, 3, 2, 1)
+    feats = []
+    for stage, n, stride in (("res2", 3, 1), ("layer2", 4, 2), ("layer3", 6, 2)):
+        for i in range(n):
+            p = f"key_encoder.{stage}.{i}"
+            s = stride if i == 0 else 1
+            idt = _conv(x, fw, p + ".downsample.0", stride=s) if i == 0 else x
+            y = F.relu(_conv(x, fw, p + ".conv1"))
+            y = F.relu(_conv(y, fw, p + ".conv2", stride=s))
+            x = F.relu(_conv(y, fw, p + ".conv3") + idt)
+        feats.append(x)
+    f4, f8, f16 = feats
+    return _conv(f16, fw, "key_proj.key_proj"), _conv(f16, fw, "key_comp"), f16, f8, f4
+
+
+def _cbam(x, fw, pre):
+    w1, b1 = fw[pre + ".ChannelGate.mlp.1"]
+    w2, b2 = fw[pre + ".ChannelGate.mlp.3"]
+
+    def mlp(v):
+        return F.linear(F.relu(F.linear(v, w1, b1)), w2, b2)
+
+    gate = torch.sigmoid(mlp(x.mean(dim=(2, 3))) + mlp(x.amax(dim=(2, 3))))
+    x = x * gate[:, :, None, None]
+    pooled = torch.stack([x.amax(dim=1), x.mean(dim=1)], 1)
+    return x * torch.sigmoid(_conv(pooled, fw, pre + ".SpatialGate.spatial.conv"))
+
+
+def encode_value(fw, img, f16, masks):
+    """img [1,3,H,W], f16 [1,1024,h,w], masks [k,1,H,W] -> values [k,512,h,w]."""
+    k = masks.shape[0]
+    others = masks.sum(0, keepdim=True) - masks if k > 1 else torch.zeros_like(masks)
+    x = torch.cat([img.expand(k, -1, -1, -1), masks, others], 1)
+    x = F.relu(_conv(x, fw, "value_encoder.conv1", stride=2))
+    x = F.max_pool2d(x, 3, 2, 1)
+    for stage, stride in (("layer1", 1), ("layer2", 2), ("layer3", 2)):
+        for i in range(2):
+            p = f"value_encoder.{stage}.{i}"
+            s = stride if i == 0 else 1
+            idt = _conv(x, fw, p + ".downsample.0", stride=s) if (p + ".downsample.0") in fw else x
+            y = F.relu(_conv(x, fw, p + ".conv1", stride=s))
+            x = F.relu(_conv(y, fw, p + ".conv2") + idt)
+    x = torch.cat([x, f16.expand(k, -1, -1, -1)], 1)
+    x = _resblock(x, fw, "value_encoder.fuser.block1")
+    x = x + _cbam(x, fw, "value_encoder.fuser.attention")
+    return _resblock(x, fw, "value_encoder.fuser.block2")
+
+
+def affinity_logits(mk, qk):
+    """mk [N,64] memory keys (rows ordered (t,h,w)), qk [Q,64] -> S [N,Q].
+    S = (2 mk.qk - |mk|^2 - |qk|^2)/sqrt(64)   (prop_net.py:86-90)."""
+    a = (mk * mk).sum(1, keepdim=True)
+    c = (qk * qk).sum(1)[None, :]
+    return (2.0 * (mk @ qk.t()) - a - c) / math.sqrt(mk.shape[1])
+
+
+def memory_read(mk, mv, qk):
+    """Sparse top-50 read.  mk [N,64], mv [k,N,512], qk [Q,64].
+    Returns (idx [Q,50] descending score, w [Q,50] softmax over the 50, readout [k,Q,512])."""
+    S = affinity_logits(mk, qk)
+    vals, idx = torch.topk(S, TOP_K, dim=0)              # [50,Q], sorted descending
+    e = torch.exp(vals - vals[0:1])
+    w = (e / e.sum(0, keepdim=True)).t().contiguous()    # [Q,50]
+    idx = idx.t().contiguous()
+    out = torch.einsum("qj,kqjc->kqc", w, mv[:, idx])    # gather 50 rows per query
+    return idx, w, out
+
+
+def decode(fw, readout, f16_thin, f8, f4):
+    """readout [k,512,h,w]; returns sigmoid probabilities [k,1,H,W] and the /4 logits."""
+    k = readout.shape[0]
+    x = torch.cat([readout, f16_thin.expand(k, -1, -1, -1)], 1)
+    x = _resblock(x, fw, "decoder.compress")
+    for up, skip in (("decoder.up_16_8", f8), ("decoder.up_8_4", f4)):
+        s = _conv(skip, fw, up + ".skip_conv").expand(k, -1, -1, -1)
+        x = s + F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
+        x = _resblock(x, fw, up + ".out_conv")
+    logit4 = _conv(x, fw, "decoder.pred", relu_in=True)
+    logit = F.interpolate(logit4, scale_factor=4, mode="bilinear", align_corners=False)
+    return torch.sigmoid(logit), logit4
+
+
+def aggregate(prob):
+    """prob [k,1,H,W] -> [k+1,1,H,W] (bg first): odds / sum(odds) after clamping."""
+    p = torch.cat([torch.prod(1 - prob, 0, keepdim=True), prob], 0).clamp(1e-7, 1 - 1e-7)
+    odds = p / (1 - p)
+    return odds / odds.sum(0, keepdim=True)
+
+
+def attention_read(mk, qk, pos, neg):
+    """Full-softmax single-frame attention transfer of the +/- mask differences.
+    mk,qk [HW,64]; pos,neg [k+1,1,H,W] -> [k+1,2,H,W]."""
+    kk, _, H, W = pos.shape
+    h, w = H // 16, W // 16
+    Wm = torch.softmax(affinity_logits(mk, qk), dim=0)                    # [HW_mem, HW_q]
+    pm = F.avg_pool2d(pos, 16).reshape(kk, h * w) @ Wm
+    nm = F.avg_pool2d(neg, 16).reshape(kk, h * w) @ Wm
+    a = torch.stack([pm, nm], 1).reshape(kk, 2, h, w)
+    return F.interpolate(a, size=(H, W), mode="bilinear", align_corners=False)
+
+
+def fusion_net(ffw, img, prev, curr, attn, nc, nr):
+    """img [1,3,H,W]; prev,curr [1,1,H,W]; attn [1,2,H,W] -> logit [1,1,H,W]."""
+    H, W = img.shape[-2:]
+    tplanes = torch.tensor([nc, nr], dtype=torch.float32).view(1, 2, 1, 1).expand(1, 2, H, W)
+    x = F.relu(_conv(torch.cat([img, prev, curr, attn, tplanes], 1), ffw, "conv1.0"))
+    for blk in ("conv2", "conv3"):
+        r = _conv(F.relu(_conv(x, ffw, blk + ".0")), ffw, blk + ".2")
+        x = F.relu(x + r)
+    return _conv(x, ffw, "final_conv")
+
+
+def pad16(x):
+    """Symmetric zero pad of the last two dims to multiples of 16 -> (padded, (lw,uw,lh,uh))."""
+    H, W = x.shape[-2:]
+    dh, dw = (-H) % 16, (-W) % 16
+    lh, lw = dh // 2, dw // 2
+    pad = (lw, dw - lw, lh, dh - lh)
+    return F.pad(x, pad), pad
+
+
+# ----------------------------------------------------------------------------------------------
+# sequence engine
+# ----------------------------------------------------------------------------------------------
+class OracleCore:
+    """Same public surface as the reference ``InferenceCore`` (ctor args, ``interact``, ``prob``,
+    ``pad``, ``t``, ``masks``, ``np_masks``, ``k``, ``nh``, ``nw``), CPU only."""
+
+    def __init__(self, prop_sd, fuse_sd, images, num_objects, mem_profile=0, mem_freq=5, device="cpu"):
+        self.fw = fold_bn(prop_sd if isinstance(prop_sd, dict) else prop_sd.state_dict())
+        self.ffw = None
+        if fuse_sd is not None:
+            self.ffw = fold_bn(fuse_sd if isinstance(fuse_sd, dict) else fuse_sd.state_dict())
+        self.mem_freq, self.k = mem_freq, num_objects
+        self.t = images.shape[1]
+        self.h, self.w = images.shape[-2:]
+        self.images, self.pad = pad16(images.detach().float().cpu())
+        self.nh, self.nw = self.images.shape[-2:]
+        self.kh, self.kw = self.nh // 16, self.nw // 16
+        self.prob = torch.zeros(self.k + 1, self.t, 1, self.nh, self.nw)
+        self.prob[0] = 1e-7
+        self.masks = torch.zeros(self.t, 1, self.nh, self.nw, dtype=torch.uint8)
+        self.np_masks = np.zeros((self.t, self.h, self.w), np.uint8)
+        self.key_cache = {}
+        self.interacted = set()
+        self.certain_k, self.certain_v = [], []     # one slot per interaction, never evicted
+        self.trace = []                              # bank sizes per pass (for tests)
+        self.stage_seconds = {}
+
+    # -- helpers --------------------------------------------------------------------------
+    def _keys(self, ti):
+        if ti not in self.key_cache:
+            if len(self.key_cache) > 105:
+                self.key_cache = {}
+            self.key_cache[ti] = encode_key(self.fw, self.images[:, ti])
+        return self.key_cache[ti]
+
+    @staticmethod
+    def _rows(x):       # [B,C,h,w] -> [B,h*w,C]
+        return x.flatten(2).transpose(1, 2).contiguous()
+
+    def _segment(self, bank_k, bank_v, ti):
+        k16, f16_thin, _f16, f8, f4 = self._keys(ti)
+        mk = torch.cat(bank_k, 0)
+        mv = torch.cat(bank_v, 1)
+        _, _, ro = memory_read(mk, mv, self._rows(k16)[0])
+        ro = ro.transpose(1, 2).reshape(self.k, 512, self.kh, self.kw)
+        prob, _ = decode(self.fw, ro, f16_thin, f8, f4)
+        return aggregate(prob)
+
+    def _sweep(self, idx, forward):
+        if forward:
+            stop = min([t for t in self.interacted if t > idx] + [self.t])
+            frames = range(idx + 1, stop)
+        else:
+            stop = max([t for t in self.interacted if t < idx] + [-1])
+            frames = range(idx - 1, stop, -1)
+        fuse = stop not in (self.t, -1)
+        bank_k, bank_v = list(self.certain_k), list(self.certain_v)
+        last = idx
+        frames = list(frames)
+        for ti in frames:
+            out = self._segment(bank_k, bank_v, ti)
+            if ti != frames[-1] and abs(ti - last) >= self.mem_freq:
+                k16, _, f16, _, _ = self._keys(ti)
+                bank_k.append(self._rows(k16)[0])
+                bank_v.append(self._rows(encode_value(self.fw, self.images[:, ti], f16, out[1:])))
+                last = ti
+            if fuse:
+                out = self._fuse(stop, idx, ti, self.prob[:, ti], out)
+            self.prob[:, ti] = out
+        self.trace.append(dict(idx=idx, forward=forward, frames=len(frames), bank=len(bank_k), fuse=fuse))
+
+    def _fuse(self, tc, tr, ti, prev, curr):
+        nc, nr = abs(tc - ti) / abs(tc - tr), abs(tr - ti) / abs(tc - tr)
+        mk = self._rows(self._keys(tr)[0])[0]
+        qk = self._rows(self._keys(ti)[0])[0]
+        attn = attention_read(mk, qk, self.pos_diff, self.neg_diff)
+        w = [torch.sigmoid(fusion_net(self.ffw, self.images[:, ti], prev[o:o + 1], curr[o:o + 1],
+                                      attn[o:o + 1], nc, nr)) for o in range(1, self.k + 1)]
+        return aggregate(torch.cat(w, 0))
+
+    # -- public ---------------------------------------------------------------------------
+    def interact(self, mask, idx, scribble=False):
+        self.interacted.add(idx)
+        mask, _ = pad16(mask.detach().float().cpu())
+        diff = mask - self.prob[:, idx]
+        self.pos_diff, self.neg_diff = diff.clamp(0, 1), (-diff).clamp(0, 1)
+        self.prob[:, idx] = mask
+        k16, _, f16, _, _ = self._keys(idx)
+        vmask = mask[1:] if scribble else mask
+        self.certain_k.append(self._rows(k16)[0])
+        self.certain_v.append(self._rows(encode_value(self.fw, self.images[:, idx], f16, vmask)))
+        self._sweep(idx, True)
+        self._sweep(idx, False)
+        self.masks[:] = torch.argmax(self.prob, dim=0).to(torch.uint8)
+        lw, uw, lh, uh = self.pad
+        m = self.masks[:, 0, lh:self.nh - uh, lw:self.nw - uw]
+        self.np_masks = m.numpy().astype(np.uint8).copy()
+        return self.np_masks
