@@ -1,0 +1,71 @@
+"""ctypes binding of libstcn_hip.so (C ABI declared in include/stcn_hip.h).
+
+The HIP library is the product: there is no CPU / PyTorch fallback.  If the shared object is missing
+the import fails loudly (build it with ``python -c 'import __graft_entry__ as g; g.build()'`` or
+``make -C eva_vos_amd/csrc``)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libstcn_hip.so")
+
+K_CLASSES = ("conv", "conv_reduce", "memread", "elementwise", "conv_n1", "other")
+
+
+class WeightDesc(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("ndim", C.c_int32), ("shape", C.c_int64 * 4)]
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("frames", "key_miss", "value_enc", "fused", "bank_fwd", "bank_bwd")]
+
+
+# name -> (restype, argtypes); kept in one table so tests can check every declared symbol is exported
+_P, _I, _F, _D = C.c_void_p, C.c_int, C.c_float, C.c_double
+PROTOTYPES = {
+    "stcn_last_error": (C.c_char_p, []),
+    "stcn_version": (C.c_char_p, []),
+    "stcn_model_create": (_I, [_I, C.POINTER(WeightDesc), _I, C.POINTER(WeightDesc), _I, C.POINTER(_P)]),
+    "stcn_model_destroy": (_I, [_P]),
+    "stcn_engine_create": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, C.POINTER(_P)]),
+    "stcn_engine_destroy": (_I, [_P]),
+    "stcn_engine_clone": (_I, [_P, _P, _P, _P, C.POINTER(_P)]),
+    "stcn_interact": (_I, [_P, _P, _I, _I, _I]),
+    "stcn_get_stats": (_I, [_P, C.POINTER(Stats)]),
+    "stcn_get_flops": (_I, [_P, C.POINTER(_D)]),
+    "stcn_test_conv": (_I, [_P, _P, _P, _P, _P, _P] + [_I] * 11),
+    "stcn_test_encode_key": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
+    "stcn_test_encode_value": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "stcn_test_memory_read": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
+    "stcn_test_decode": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
+    "stcn_test_attention": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "stcn_test_fusion": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _I, _I, _P]),
+    "stcn_bench_conv": (_I, [_P] + [_I] * 11 + [C.POINTER(_F), C.POINTER(_D)]),
+    "stcn_engine_set_profiling": (_I, [_P, _I]),
+    "stcn_get_kernel_ms": (_I, [_P, C.POINTER(_F), C.POINTER(C.c_int32)]),
+    "stcn_get_kernel_flops": (_I, [_P, C.POINTER(_D)]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: the HIP engine has not been built (run __graft_entry__.build() "
+                "or `make -C eva_vos_amd/csrc`).  There is no CPU fallback.")
+        _lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(_lib, name)
+            fn.restype, fn.argtypes = res, args
+    return _lib
+
+
+def check(rc: int, what: str = "stcn") -> None:
+    if rc != 0:
+        msg = lib().stcn_last_error()
+        raise RuntimeError(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")

@@ -1,0 +1,704 @@
+// engine.cpp - model build (BN fold + repack), stage graphs and the per-video interact() state machine.
+// Host logic only; every device computation is a kernel of conv_gemm.hip / elementwise.hip / memread.hip.
+// Reference behaviour: mivos/inference_core.py (InferenceCore), mivos/model/propagation/*.py.
+#include "engine.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+namespace stcn {
+
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+const char *get_error() { return g_err; }
+
+// ---------------------------------------------------------------------------------------------- Prof
+void Prof::reset() {
+    for (int i = 0; i < STCN_K_COUNT; ++i) { flops[i] = 0; launches[i] = 0; }
+    for (auto &e : events) { pool.push_back(e.a); pool.push_back(e.b); }
+    events.clear();
+}
+void Prof::begin(int cls, hipStream_t s) {
+    launches[cls]++;
+    if (!on) return;
+    Ev e; e.cls = cls;
+    for (hipEvent_t *p : {&e.a, &e.b}) {
+        if (!pool.empty()) { *p = pool.back(); pool.pop_back(); }
+        else (void)hipEventCreate(p);
+    }
+    (void)hipEventRecord(e.a, s);
+    events.push_back(e);
+}
+void Prof::end(hipStream_t s) {
+    if (!on) return;
+    (void)hipEventRecord(events.back().b, s);
+}
+int Prof::collect(float *ms) {
+    for (int i = 0; i < STCN_K_COUNT; ++i) ms[i] = 0.f;
+    for (auto &e : events) {
+        if (hipEventSynchronize(e.b) != hipSuccess) return STCN_E_HIP;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, e.a, e.b) != hipSuccess) return STCN_E_HIP;
+        ms[e.cls] += t;
+    }
+    return STCN_OK;
+}
+Prof::~Prof() {
+    for (auto &e : events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (auto &p : pool) (void)hipEventDestroy(p);
+}
+struct Scope {
+    Prof *p; hipStream_t s;
+    Scope(Prof *p_, int cls, hipStream_t s_, double fl = 0) : p(p_), s(s_) {
+        if (p) { p->flops[cls] += fl; p->begin(cls, s); }
+    }
+    ~Scope() { if (p) p->end(s); }
+};
+
+// ---------------------------------------------------------------------------------------------- Model
+const ConvW &Model::c(const std::string &name) const {
+    auto it = conv.find(name);
+    if (it == conv.end()) { static ConvW empty; set_error("missing conv '%s'", name.c_str()); return empty; }
+    return it->second;
+}
+
+struct HostT { const float *p; int nd; int64_t sh[4]; };
+
+static int upload(Model &m, const std::vector<float> &h, float **dev) {
+    HIPCHK(hipMalloc((void **)dev, h.size() * sizeof(float)));
+    m.allocs.push_back(*dev);
+    HIPCHK(hipMemcpy(*dev, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    return STCN_OK;
+}
+
+static int add_convs(Model &m, const std::map<std::string, HostT> &sd) {
+    for (auto &kv : sd) {
+        const std::string &name = kv.first;
+        if (name.size() < 8 || name.compare(name.size() - 7, 7, ".weight") != 0 || kv.second.nd != 4) continue;
+        const std::string pre = name.substr(0, name.size() - 7);
+        const HostT &wt = kv.second;
+        const int cout = (int)wt.sh[0], cin = (int)wt.sh[1], kh = (int)wt.sh[2], kw = (int)wt.sh[3];
+        // BatchNorm that follows: "X.convN" -> "X.bnN", "X.downsample.0" -> "X.downsample.1"
+        std::string bn;
+        const size_t dot = pre.rfind('.');
+        const std::string leaf = pre.substr(dot + 1), head = pre.substr(0, dot);
+        if (leaf.compare(0, 4, "conv") == 0) bn = head + ".bn" + leaf.substr(4);
+        else if (leaf == "0") bn = head + ".1";
+        const bool has_bn = !bn.empty() && sd.count(bn + ".running_mean");
+        std::vector<float> scale(cout, 1.f), bias(cout, 0.f);
+        auto bit = sd.find(pre + ".bias");
+        if (bit != sd.end()) for (int n = 0; n < cout; ++n) bias[n] = bit->second.p[n];
+        if (has_bn) {
+            const float *g = sd.at(bn + ".weight").p, *b = sd.at(bn + ".bias").p;
+            const float *mu = sd.at(bn + ".running_mean").p, *var = sd.at(bn + ".running_var").p;
+            for (int n = 0; n < cout; ++n) {
+                const float sc = g[n] / std::sqrt(var[n] + 1e-5f);
+                scale[n] = sc;
+                bias[n] = (bias[n] - mu[n]) * sc + b[n];
+            }
+        }
+        ConvW cw;
+        cw.cout = cout; cw.cin = cin; cw.kh = kh; cw.kw = kw;
+        cw.cin_p = (cin + 3) / 4 * 4;
+        cw.K = kh * kw * cw.cin_p;
+        cw.Kp = (cw.K + 31) / 32 * 32;
+        std::vector<float> w((size_t)cout * cw.Kp, 0.f);
+        for (int n = 0; n < cout; ++n)
+            for (int c = 0; c < cin; ++c)
+                for (int y = 0; y < kh; ++y)
+                    for (int x = 0; x < kw; ++x)
+                        w[(size_t)n * cw.Kp + (size_t)(y * kw + x) * cw.cin_p + c] =
+                            wt.p[(((size_t)n * cin + c) * kh + y) * kw + x] * scale[n];
+        int rc = upload(m, w, &cw.w);
+        if (rc) return rc;
+        rc = upload(m, bias, &cw.bias);
+        if (rc) return rc;
+        cw.bias0 = bias[0];
+        m.conv[pre] = cw;
+    }
+    return STCN_OK;
+}
+
+static int build_model(Model &m, const stcn_weight_desc *prop, int n_prop, const stcn_weight_desc *fuse, int n_fuse) {
+    std::map<std::string, HostT> sd;
+    for (int i = 0; i < n_prop; ++i) {
+        if (!prop[i].name || !prop[i].data || prop[i].ndim < 0 || prop[i].ndim > 4) {
+            set_error("bad weight descriptor %d", i);
+            return STCN_E_INVALID;
+        }
+        HostT t{prop[i].data, prop[i].ndim, {1, 1, 1, 1}};
+        for (int d = 0; d < prop[i].ndim; ++d) t.sh[d] = prop[i].shape[d];
+        sd[prop[i].name] = t;
+    }
+    int rc = add_convs(m, sd);
+    if (rc) return rc;
+    static const char *required[] = {
+        "key_encoder.conv1", "key_encoder.res2.0.downsample.0", "key_encoder.layer3.5.conv3", "key_proj.key_proj",
+        "key_comp", "value_encoder.conv1", "value_encoder.layer3.1.conv2", "value_encoder.fuser.block1.downsample",
+        "value_encoder.fuser.block2.conv2", "decoder.compress.downsample", "decoder.up_16_8.skip_conv",
+        "decoder.up_16_8.out_conv.downsample", "decoder.up_8_4.out_conv.conv2", "decoder.pred"};
+    for (const char *r : required)
+        if (!m.conv.count(r)) { set_error("state_dict lacks '%s.weight'", r); return STCN_E_MISSING; }
+    // CBAM
+    const char *cb = "value_encoder.fuser.attention.";
+    auto need = [&](const std::string &n) -> const HostT * {
+        auto it = sd.find(std::string(cb) + n);
+        if (it == sd.end()) { set_error("state_dict lacks '%s%s'", cb, n.c_str()); return nullptr; }
+        return &it->second;
+    };
+    const HostT *w1 = need("ChannelGate.mlp.1.weight"), *b1 = need("ChannelGate.mlp.1.bias");
+    const HostT *w2 = need("ChannelGate.mlp.3.weight"), *b2 = need("ChannelGate.mlp.3.bias");
+    const HostT *ws = need("SpatialGate.spatial.conv.weight"), *bs = need("SpatialGate.spatial.conv.bias");
+    if (!w1 || !b1 || !w2 || !b2 || !ws || !bs) return STCN_E_MISSING;
+    float *d;
+    auto up = [&](const HostT *t, size_t n, const float **dst) -> int {
+        std::vector<float> h(t->p, t->p + n);
+        int r = upload(m, h, &d);
+        *dst = d;
+        return r;
+    };
+    if ((rc = up(w1, 32 * 512, &m.cbam.w1)) || (rc = up(b1, 32, &m.cbam.b1)) || (rc = up(w2, 512 * 32, &m.cbam.w2)) ||
+        (rc = up(b2, 512, &m.cbam.b2)) || (rc = up(ws, 98, &m.cbam.wsp)))
+        return rc;
+    m.cbam.bsp = bs->p[0];
+    // fusion net (names do not collide with the propagation network's)
+    if (fuse && n_fuse > 0) {
+        std::map<std::string, HostT> fsd;
+        for (int i = 0; i < n_fuse; ++i) {
+            HostT t{fuse[i].data, fuse[i].ndim, {1, 1, 1, 1}};
+            for (int dd = 0; dd < fuse[i].ndim; ++dd) t.sh[dd] = fuse[i].shape[dd];
+            fsd[std::string("fuse.") + fuse[i].name] = t;
+        }
+        if ((rc = add_convs(m, fsd))) return rc;
+        for (const char *r : {"fuse.conv1.0", "fuse.conv2.0", "fuse.conv2.2", "fuse.conv3.0", "fuse.conv3.2", "fuse.final_conv"})
+            if (!m.conv.count(r)) { set_error("fusion state_dict lacks '%s.weight'", r + 5); return STCN_E_MISSING; }
+        m.has_fuse = true;
+    }
+    return STCN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- Work
+int Work::init(int nh, int nw, int k_) {
+    d.set(nh, nw);
+    k = k_;
+    auto alloc = [&](void **p, size_t bytes) -> int {
+        HIPCHK(hipMalloc(p, bytes));
+        allocs.push_back(*p);
+        return STCN_OK;
+    };
+    const size_t s1 = (size_t)k * d.hw2 * 64, s2 = (size_t)d.npix * 32, s3 = (size_t)k * d.hw4 * 256;
+    S = s1 > s2 ? s1 : s2;
+    S = S > s3 ? S : s3;
+    int rc;
+    for (float **b : {&A, &B, &C, &D})
+        if ((rc = alloc((void **)b, S * sizeof(float)))) return rc;
+    splitk_floats = (size_t)32 * 1024 * 1024;      // 128 MB of fp32 slabs; conv falls back to fewer splits
+    if ((rc = alloc((void **)&splitk, splitk_floats * sizeof(float)))) return rc;
+    if ((rc = alloc((void **)&cbam, (size_t)k * (1024 + 512 + 3 * d.hw16) * sizeof(float)))) return rc;
+    if ((rc = alloc((void **)&readout, (size_t)k * d.hw16 * 512 * sizeof(float)))) return rc;
+    if ((rc = alloc((void **)&logit4, (size_t)k * d.hw4 * sizeof(float)))) return rc;
+    if ((rc = alloc((void **)&flogit, (size_t)k * d.npix * sizeof(float)))) return rc;
+    if ((rc = alloc((void **)&agg, (size_t)(k + 1) * d.npix * sizeof(float)))) return rc;
+    if ((rc = alloc((void **)&pooled, (size_t)(k + 1) * 2 * d.hw16 * sizeof(float)))) return rc;
+    if ((rc = alloc((void **)&amap, (size_t)(k + 1) * 2 * d.hw16 * sizeof(float)))) return rc;
+    if ((rc = alloc((void **)&attn, (size_t)(k + 1) * 2 * d.npix * sizeof(float)))) return rc;
+    if ((rc = alloc((void **)&cand_v, (size_t)16 * d.hw16 * 50 * sizeof(float)))) return rc;
+    if ((rc = alloc((void **)&cand_i, (size_t)16 * d.hw16 * 50 * sizeof(int32_t)))) return rc;
+    if ((rc = alloc((void **)&vin, (size_t)k * d.npix * 8 * sizeof(float)))) return rc;
+    return STCN_OK;
+}
+void Work::release() {
+    for (void *p : allocs) (void)hipFree(p);
+    allocs.clear();
+}
+
+// ---------------------------------------------------------------------------------------------- stages
+int run_conv(const Model &m, Work &w, hipStream_t s, const char *name, const float *x0, int c0, long bs0,
+             const float *x1, int c1, long bs1, int B, int H, int W, int stride, float *y, long y_bs,
+             const float *res, long res_bs, int relu_in, int relu_out, int force_splitk) {
+    auto it = m.conv.find(name);
+    if (it == m.conv.end()) { set_error("missing conv '%s'", name); return STCN_E_MISSING; }
+    const ConvW &cw = it->second;
+    if (c0 + c1 != cw.cin_p) { set_error("conv '%s': %d+%d input channels, weights have %d", name, c0, c1, cw.cin_p); return STCN_E_INVALID; }
+    ConvP p{};
+    p.x0 = x0; p.x1 = x1; p.c0 = c0; p.c1 = c1; p.bs0 = bs0; p.bs1 = bs1;
+    p.B = B; p.H = H; p.W = W;
+    p.KH = cw.kh; p.KW = cw.kw; p.stride = stride; p.pad = cw.kh / 2;
+    p.OH = (H + 2 * p.pad - cw.kh) / stride + 1;
+    p.OW = (W + 2 * p.pad - cw.kw) / stride + 1;
+    p.Cin = cw.cin_p;
+    p.M = B * p.OH * p.OW; p.N = cw.cout; p.K = cw.K; p.Kp = cw.Kp;
+    p.w = cw.w; p.bias = cw.bias; p.res = res; p.res_bs = res_bs; p.y = y; p.y_bs = y_bs;
+    p.relu_in = relu_in; p.relu_out = relu_out;
+    p.splitk = force_splitk > 0 ? force_splitk : conv_choose_splitk(p);
+    while (p.splitk > 1 && (size_t)p.splitk * p.M * p.N > w.splitk_floats) --p.splitk;
+    p.partial = w.splitk;
+    const double fl = 2.0 * p.M * p.N * (double)(cw.kh * cw.kw * cw.cin);
+    Scope sc(w.prof, STCN_K_CONV, s, fl);
+    conv_launch(p, s);
+    return STCN_OK;
+}
+
+#define RC(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+
+static int conv1(const Model &m, Work &w, hipStream_t s, const std::string &name, const float *x, int cin, int B,
+                 int H, int W, int stride, float *y, const float *res, int relu_in, int relu_out) {
+    const ConvW &cw = m.c(name);
+    const int OH = (H + 2 * (cw.kh / 2) - cw.kh) / stride + 1, OW = (W + 2 * (cw.kw / 2) - cw.kw) / stride + 1;
+    return run_conv(m, w, s, name.c_str(), x, cin, (long)H * W * cin, nullptr, 0, 0, B, H, W, stride, y, 0, res,
+                    (long)OH * OW * cw.cout, relu_in, relu_out);
+}
+
+// KeyEncoder (modules.py:127-149) + key_proj/key_comp (prop_net.py:172-177) + decoder skip convs
+int encode_key(const Model &m, Work &w, hipStream_t s, const float *img4, const KeyOut &o) {
+    const Dims &d = w.d;
+    RC(conv1(m, w, s, "key_encoder.conv1", img4, 4, 1, d.nh, d.nw, 2, w.A, nullptr, 0, 1));
+    { Scope sc(w.prof, STCN_K_ELEMWISE, s); maxpool3x3s2_launch(w.A, w.B, 1, d.h2, d.w2, 64, s); }
+    struct St { const char *name; int n, planes, stride; } stages[3] = {{"res2", 3, 64, 1}, {"layer2", 4, 128, 2}, {"layer3", 6, 256, 2}};
+    int H = d.h4, W = d.w4, cin = 64;
+    float *x = w.B;
+    for (int si = 0; si < 3; ++si) {
+        const St &st = stages[si];
+        for (int i = 0; i < st.n; ++i) {
+            const std::string p = std::string("key_encoder.") + st.name + "." + std::to_string(i);
+            const int sd = i == 0 ? st.stride : 1;
+            const int OH = H / sd, OW = W / sd;
+            const float *idt = x;
+            if (i == 0) { RC(conv1(m, w, s, p + ".downsample.0", x, cin, 1, H, W, sd, w.D, nullptr, 0, 0)); idt = w.D; }
+            RC(conv1(m, w, s, p + ".conv1", x, cin, 1, H, W, 1, w.C, nullptr, 0, 1));
+            RC(conv1(m, w, s, p + ".conv2", w.C, st.planes, 1, H, W, sd, w.A, nullptr, 0, 1));
+            float *dst = x;
+            if (si == 2 && i == st.n - 1) dst = o.f16;
+            RC(conv1(m, w, s, p + ".conv3", w.A, st.planes, 1, OH, OW, 1, dst, idt, 0, 1));
+            x = dst; H = OH; W = OW; cin = st.planes * 4;
+        }
+        if (si == 0) {
+            if (o.f4_copy) HIPCHK(hipMemcpyAsync(o.f4_copy, x, (size_t)d.hw4 * 256 * 4, hipMemcpyDeviceToDevice, s));
+            if (o.s4) RC(conv1(m, w, s, "decoder.up_8_4.skip_conv", x, 256, 1, d.h4, d.w4, 1, o.s4, nullptr, 0, 0));
+        } else if (si == 1) {
+            if (o.f8_copy) HIPCHK(hipMemcpyAsync(o.f8_copy, x, (size_t)d.hw8 * 512 * 4, hipMemcpyDeviceToDevice, s));
+            if (o.s8) RC(conv1(m, w, s, "decoder.up_16_8.skip_conv", x, 512, 1, d.h8, d.w8, 1, o.s8, nullptr, 0, 0));
+        }
+    }
+    if (o.k16) {
+        RC(conv1(m, w, s, "key_proj.key_proj", o.f16, 1024, 1, d.h16, d.w16, 1, o.k16, nullptr, 0, 0));
+        if (o.msq) { Scope sc(w.prof, STCN_K_ELEMWISE, s); rowsumsq_launch(o.k16, d.hw16, 64, o.msq, s); }
+    }
+    if (o.f16_thin) RC(conv1(m, w, s, "key_comp", o.f16, 1024, 1, d.h16, d.w16, 1, o.f16_thin, nullptr, 0, 0));
+    return STCN_OK;
+}
+
+// pre-activation ResBlock (modules.py:15-35) over a (possibly two-source) input
+static int resblock(const Model &m, Work &w, hipStream_t s, const std::string &p, const float *x0, int c0, long bs0,
+                    const float *x1, int c1, long bs1, int B, int H, int W, float *t1, float *t2, float *out,
+                    long out_bs) {
+    const ConvW &cw = m.c(p + ".conv1");
+    const long obs = (long)H * W * cw.cout;
+    const float *skip; long skip_bs;
+    if (m.conv.count(p + ".downsample")) {
+        RC(run_conv(m, w, s, (p + ".downsample").c_str(), x0, c0, bs0, x1, c1, bs1, B, H, W, 1, t2, 0, nullptr, 0, 0, 0));
+        skip = t2; skip_bs = obs;
+    } else { skip = x0; skip_bs = bs0; }
+    RC(run_conv(m, w, s, (p + ".conv1").c_str(), x0, c0, bs0, x1, c1, bs1, B, H, W, 1, t1, 0, nullptr, 0, 1, 0));
+    RC(run_conv(m, w, s, (p + ".conv2").c_str(), t1, cw.cout, obs, nullptr, 0, 0, B, H, W, 1, out, out_bs, skip, skip_bs, 1, 0));
+    return STCN_OK;
+}
+
+// ValueEncoder (modules.py:93-124, mod_resnet.py:49-78) + FeatureFusionBlock (modules.py:38-52)
+int encode_value(const Model &m, Work &w, hipStream_t s, const float *img4, const float *f16, const float *masks,
+                 long mask_stride, float *out, long out_bs) {
+    const Dims &d = w.d;
+    const int k = w.k;
+    { Scope sc(w.prof, STCN_K_ELEMWISE, s); pack_value_input_launch(img4, masks, mask_stride, k, (int)d.npix, w.vin, s); }
+    RC(conv1(m, w, s, "value_encoder.conv1", w.vin, 8, k, d.nh, d.nw, 2, w.C, nullptr, 0, 1));
+    { Scope sc(w.prof, STCN_K_ELEMWISE, s); maxpool3x3s2_launch(w.C, w.B, k, d.h2, d.w2, 64, s); }
+    int H = d.h4, W = d.w4, cin = 64;
+    const int planes[3] = {64, 128, 256}, strides[3] = {1, 2, 2};
+    for (int li = 0; li < 3; ++li)
+        for (int i = 0; i < 2; ++i) {
+            const std::string p = "value_encoder.layer" + std::to_string(li + 1) + "." + std::to_string(i);
+            const int sd = i == 0 ? strides[li] : 1;
+            const int OH = H / sd, OW = W / sd;
+            const float *idt = w.B;
+            if (m.conv.count(p + ".downsample.0")) {
+                RC(conv1(m, w, s, p + ".downsample.0", w.B, cin, k, H, W, sd, w.D, nullptr, 0, 0));
+                idt = w.D;
+            }
+            RC(conv1(m, w, s, p + ".conv1", w.B, cin, k, H, W, sd, w.C, nullptr, 0, 1));
+            RC(conv1(m, w, s, p + ".conv2", w.C, planes[li], k, OH, OW, 1, w.B, idt, 0, 1));
+            H = OH; W = OW; cin = planes[li];
+        }
+    // fuser: block1(cat[x256, f16]) -> x + CBAM(x) -> block2
+    const std::string f = "value_encoder.fuser.";
+    RC(resblock(m, w, s, f + "block1", w.B, 256, (long)d.hw16 * 256, f16, 1024, 0, k, d.h16, d.w16, w.C, w.D, w.A, 0));
+    { Scope sc(w.prof, STCN_K_OTHER, s); cbam_launch(w.A, w.C, k, d.h16, d.w16, m.cbam, w.cbam, s); }
+    RC(resblock(m, w, s, f + "block2", w.C, 512, (long)d.hw16 * 512, nullptr, 0, 0, k, d.h16, d.w16, w.D, w.A, out, out_bs));
+    return STCN_OK;
+}
+
+// Decoder (prop_net.py:13-30) on cat[readout, f16_thin] + sigmoid + aggregate_wbg
+int decode(const Model &m, Work &w, hipStream_t s, const float *readout, const float *f16_thin, const float *s8,
+           const float *s4, float *agg, long agg_stride) {
+    const Dims &d = w.d;
+    const int k = w.k;
+    RC(resblock(m, w, s, "decoder.compress", readout, 512, (long)d.hw16 * 512, f16_thin, 512, 0, k, d.h16, d.w16, w.C,
+                w.D, w.A, 0));
+    { Scope sc(w.prof, STCN_K_ELEMWISE, s); upsample2x_add_launch(w.A, s8, w.B, k, d.h16, d.w16, 512, s); }
+    RC(resblock(m, w, s, "decoder.up_16_8.out_conv", w.B, 512, (long)d.hw8 * 512, nullptr, 0, 0, k, d.h8, d.w8, w.C, w.D,
+                w.A, 0));
+    { Scope sc(w.prof, STCN_K_ELEMWISE, s); upsample2x_add_launch(w.A, s4, w.B, k, d.h8, d.w8, 256, s); }
+    RC(resblock(m, w, s, "decoder.up_8_4.out_conv", w.B, 256, (long)d.hw4 * 256, nullptr, 0, 0, k, d.h4, d.w4, w.C, w.D,
+                w.A, 0));
+    const ConvW &pw = m.c("decoder.pred");
+    {
+        Scope sc(w.prof, STCN_K_CONV_N1, s, 2.0 * k * d.hw4 * 9 * 256);
+        conv_n1_launch(w.A, pw.w, pw.bias0, w.logit4, k, d.h4, d.w4, 256, 3, 1, s);
+    }
+    { Scope sc(w.prof, STCN_K_ELEMWISE, s); up4_sigmoid_aggregate_launch(w.logit4, k, d.h4, d.w4, agg, agg_stride, s); }
+    return STCN_OK;
+}
+
+// FusionNet.forward (fusion_net.py:32-50) for one object
+int fusion_logit(const Model &m, Work &w, hipStream_t s, const float *img4, const float *prev, const float *curr,
+                 const float *attn2, float nc, float nr, float *logit) {
+    if (!m.has_fuse) { set_error("model was built without a fusion network"); return STCN_E_STATE; }
+    const Dims &d = w.d;
+    { Scope sc(w.prof, STCN_K_ELEMWISE, s); pack_fusion_input_launch(img4, prev, curr, attn2, nc, nr, d.npix, w.A, s); }
+    RC(conv1(m, w, s, "fuse.conv1.0", w.A, 12, 1, d.nh, d.nw, 1, w.B, nullptr, 0, 1));
+    RC(conv1(m, w, s, "fuse.conv2.0", w.B, 32, 1, d.nh, d.nw, 1, w.C, nullptr, 0, 1));
+    RC(conv1(m, w, s, "fuse.conv2.2", w.C, 32, 1, d.nh, d.nw, 1, w.D, w.B, 0, 1));
+    RC(conv1(m, w, s, "fuse.conv3.0", w.D, 32, 1, d.nh, d.nw, 1, w.C, nullptr, 0, 1));
+    RC(conv1(m, w, s, "fuse.conv3.2", w.C, 32, 1, d.nh, d.nw, 1, w.B, w.D, 0, 1));
+    const ConvW &fw = m.c("fuse.final_conv");
+    Scope sc(w.prof, STCN_K_CONV_N1, s, 2.0 * d.npix * 9 * 32);
+    conv_n1_launch(w.B, fw.w, fw.bias0, logit, 1, d.nh, d.nw, 32, 3, 0, s);
+    return STCN_OK;
+}
+
+}  // namespace stcn
+
+// =============================================================================================== C ABI
+using namespace stcn;
+
+extern "C" {
+
+const char *stcn_last_error(void) { return stcn::get_error(); }
+const char *stcn_version(void) { return "stcn_hip 0.1 (gfx950, fp32 MFMA)"; }
+
+int stcn_model_create(int device, const stcn_weight_desc *prop, int n_prop, const stcn_weight_desc *fuse, int n_fuse,
+                      stcn_model **out) {
+    if (!prop || n_prop <= 0 || !out) { set_error("stcn_model_create: null arguments"); return STCN_E_INVALID; }
+    HIPCHK(hipSetDevice(device));
+    stcn_model *mm = new stcn_model();
+    mm->m.device = device;
+    const int rc = build_model(mm->m, prop, n_prop, fuse, n_fuse);
+    if (rc) { stcn_model_destroy(mm); return rc; }
+    *out = mm;
+    return STCN_OK;
+}
+
+int stcn_model_destroy(stcn_model *m) {
+    if (!m) return STCN_OK;
+    for (void *p : m->m.allocs) (void)hipFree(p);
+    delete m;
+    return STCN_OK;
+}
+
+// ---- engine -------------------------------------------------------------------------------------
+static int eng_alloc(stcn_engine *e, void **p, size_t bytes) {
+    HIPCHK(hipMalloc(p, bytes));
+    e->allocs.push_back(*p);
+    return STCN_OK;
+}
+
+struct SlotPtrs { float *k16, *msq, *f16_thin, *f16, *s8, *s4; };
+static SlotPtrs slot_ptrs(const stcn_engine *e, int slot) {
+    const Dims &d = e->d;
+    float *b = e->cache + (size_t)slot * e->slot_floats;
+    SlotPtrs p;
+    p.k16 = b; b += (size_t)d.hw16 * 64;
+    p.msq = b; b += (size_t)(d.hw16 + 3) / 4 * 4;
+    p.f16_thin = b; b += (size_t)d.hw16 * 512;
+    p.f16 = b; b += (size_t)d.hw16 * 1024;
+    p.s8 = b; b += (size_t)d.hw8 * 512;
+    p.s4 = b;
+    return p;
+}
+
+static int bank_reserve(stcn_engine *e, int slots) {
+    if (slots <= e->bank_cap) return STCN_OK;
+    const Dims &d = e->d;
+    int cap = e->bank_cap ? e->bank_cap : 8;
+    while (cap < slots) cap *= 2;
+    float *nk, *nq, *nv;
+    const size_t rows = (size_t)cap * d.hw16;
+    HIPCHK(hipMalloc((void **)&nk, rows * 64 * 4));
+    HIPCHK(hipMalloc((void **)&nq, rows * 4));
+    HIPCHK(hipMalloc((void **)&nv, (size_t)e->k * rows * 512 * 4));
+    if (e->n_certain > 0) {
+        const size_t crow = (size_t)e->n_certain * d.hw16, orow = (size_t)e->bank_cap * d.hw16;
+        HIPCHK(hipMemcpyAsync(nk, e->bank_k, crow * 64 * 4, hipMemcpyDeviceToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(nq, e->bank_msq, crow * 4, hipMemcpyDeviceToDevice, e->stream));
+        for (int o = 0; o < e->k; ++o)
+            HIPCHK(hipMemcpyAsync(nv + o * rows * 512, e->bank_v + o * orow * 512, crow * 512 * 4,
+                                  hipMemcpyDeviceToDevice, e->stream));
+    }
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->bank_k) { (void)hipFree(e->bank_k); (void)hipFree(e->bank_msq); (void)hipFree(e->bank_v); }
+    e->bank_k = nk; e->bank_msq = nq; e->bank_v = nv; e->bank_cap = cap;
+    return STCN_OK;
+}
+
+static int engine_alloc_common(stcn_engine *e) {
+    const Dims &d = e->d;
+    RC(eng_alloc(e, (void **)&e->images4, (size_t)e->T * d.npix * 4 * 4));
+    e->n_slots = e->T < 106 ? e->T : 106;                 // key_buf holds at most 106 frames (inference_core.py:46,118)
+    e->slot_floats = (size_t)d.hw16 * (64 + 512 + 1024) + (size_t)(d.hw16 + 3) / 4 * 4 + (size_t)d.hw8 * 512 + (size_t)d.hw4 * 256;
+    RC(eng_alloc(e, (void **)&e->cache, (size_t)e->n_slots * e->slot_floats * 4));
+    e->slot_of.assign(e->T, -1);
+    RC(eng_alloc(e, (void **)&e->mask_pad, (size_t)(e->k + 1) * d.npix * 4));
+    RC(eng_alloc(e, (void **)&e->pos, (size_t)(e->k + 1) * d.npix * 4));
+    RC(eng_alloc(e, (void **)&e->neg, (size_t)(e->k + 1) * d.npix * 4));
+    RC(e->work.init(d.nh, d.nw, e->k));
+    e->work.prof = &e->prof;
+    return STCN_OK;
+}
+
+int stcn_engine_create(const stcn_model *m, int T, int H, int W, int k, int mem_freq, void *stream,
+                       const float *images_dev, float *prob_dev, uint8_t *masks_dev, stcn_engine **out) {
+    if (!m || !images_dev || !prob_dev || !masks_dev || !out) { set_error("stcn_engine_create: null arguments"); return STCN_E_INVALID; }
+    if (T < 1 || H < 16 || W < 16 || k < 1 || k > 8 || mem_freq < 1) {
+        set_error("stcn_engine_create: bad shape T=%d H=%d W=%d k=%d mem_freq=%d (1<=k<=8)", T, H, W, k, mem_freq);
+        return STCN_E_INVALID;
+    }
+    HIPCHK(hipSetDevice(m->m.device));
+    stcn_engine *e = new stcn_engine();
+    e->model = &m->m; e->stream = (hipStream_t)stream;
+    e->T = T; e->H = H; e->W = W; e->k = k; e->mem_freq = mem_freq;
+    const int nh = (H + 15) / 16 * 16, nw = (W + 15) / 16 * 16;
+    e->lh = (nh - H) / 2; e->uh = nh - H - e->lh; e->lw = (nw - W) / 2; e->uw = nw - W - e->lw;
+    e->d.set(nh, nw);
+    if ((long)e->d.hw16 < 50) { set_error("frame too small: (H/16)*(W/16) must be >= 50 for the top-50 read"); delete e; return STCN_E_INVALID; }
+    e->prob = prob_dev; e->masks = masks_dev;
+    int rc = engine_alloc_common(e);
+    if (!rc) rc = bank_reserve(e, (T - 1) / mem_freq + 1 + 8);
+    if (rc) { stcn_engine_destroy(e); return rc; }
+    const Dims &d = e->d;
+    for (int t = 0; t < T; ++t)
+        pack_image_launch(images_dev + (size_t)t * 3 * H * W, e->images4 + (size_t)t * d.npix * 4, H, W, nh, nw, e->lw, e->lh, e->stream);
+    // prob: bg row 1e-7, object rows 0 (inference_core.py:86-87)
+    fill_launch(prob_dev, 1e-7f, (long)T * d.npix, e->stream);
+    fill_launch(prob_dev + (size_t)T * d.npix, 0.f, (long)k * T * d.npix, e->stream);
+    HIPCHK(hipMemsetAsync(masks_dev, 0, (size_t)T * d.npix, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));   // images_dev may be released by the caller after return
+    *out = e;
+    return STCN_OK;
+}
+
+int stcn_engine_destroy(stcn_engine *e) {
+    if (!e) return STCN_OK;
+    if (e->stream) (void)hipStreamSynchronize(e->stream); else (void)hipDeviceSynchronize();
+    for (void *p : e->allocs) (void)hipFree(p);
+    if (e->bank_k) { (void)hipFree(e->bank_k); (void)hipFree(e->bank_msq); (void)hipFree(e->bank_v); }
+    e->work.release();
+    delete e;
+    return STCN_OK;
+}
+
+int stcn_engine_clone(const stcn_engine *src, float *prob_dev, uint8_t *masks_dev, void *stream, stcn_engine **out) {
+    if (!src || !prob_dev || !masks_dev || !out) { set_error("stcn_engine_clone: null arguments"); return STCN_E_INVALID; }
+    HIPCHK(hipSetDevice(src->model->device));
+    stcn_engine *e = new stcn_engine();
+    e->model = src->model; e->stream = (hipStream_t)stream;
+    e->T = src->T; e->H = src->H; e->W = src->W; e->k = src->k; e->mem_freq = src->mem_freq;
+    e->lw = src->lw; e->uw = src->uw; e->lh = src->lh; e->uh = src->uh; e->d = src->d;
+    e->prob = prob_dev; e->masks = masks_dev;
+    int rc = engine_alloc_common(e);
+    if (!rc) rc = bank_reserve(e, src->bank_cap);
+    if (rc) { stcn_engine_destroy(e); return rc; }
+    const Dims &d = e->d;
+    HIPCHK(hipStreamSynchronize(src->stream));
+    HIPCHK(hipMemcpyAsync(e->images4, src->images4, (size_t)e->T * d.npix * 16, hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->cache, src->cache, (size_t)e->n_slots * e->slot_floats * 4, hipMemcpyDeviceToDevice, e->stream));
+    e->slot_of = src->slot_of; e->n_cached = src->n_cached;
+    e->n_certain = src->n_certain; e->interacted = src->interacted;
+    const size_t crow = (size_t)e->n_certain * d.hw16;
+    if (crow) {
+        HIPCHK(hipMemcpyAsync(e->bank_k, src->bank_k, crow * 64 * 4, hipMemcpyDeviceToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(e->bank_msq, src->bank_msq, crow * 4, hipMemcpyDeviceToDevice, e->stream));
+        for (int o = 0; o < e->k; ++o)
+            HIPCHK(hipMemcpyAsync(e->bank_v + (size_t)o * e->bank_cap * d.hw16 * 512,
+                                  src->bank_v + (size_t)o * src->bank_cap * d.hw16 * 512, crow * 512 * 4,
+                                  hipMemcpyDeviceToDevice, e->stream));
+    }
+    HIPCHK(hipMemcpyAsync(e->pos, src->pos, (size_t)(e->k + 1) * d.npix * 4, hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->neg, src->neg, (size_t)(e->k + 1) * d.npix * 4, hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    *out = e;
+    return STCN_OK;
+}
+
+// key features of frame ti (cached; inference_core.py:115-124)
+static int ensure_key(stcn_engine *e, int ti, SlotPtrs *out) {
+    if (e->slot_of[ti] < 0) {
+        if (e->n_cached >= e->n_slots) {                     // flush-all policy of the reference
+            std::fill(e->slot_of.begin(), e->slot_of.end(), -1);
+            e->n_cached = 0;
+        }
+        const int slot = e->n_cached++;
+        e->slot_of[ti] = slot;
+        const SlotPtrs p = slot_ptrs(e, slot);
+        KeyOut ko{p.k16, p.msq, p.f16_thin, p.f16, p.s8, p.s4, nullptr, nullptr};
+        RC(encode_key(*e->model, e->work, e->stream, e->images4 + (size_t)ti * e->d.npix * 4, ko));
+        e->stats.key_miss++;
+    }
+    *out = slot_ptrs(e, e->slot_of[ti]);
+    return STCN_OK;
+}
+
+static float *bank_v_slot(stcn_engine *e, int slot) { return e->bank_v + (size_t)slot * e->d.hw16 * 512; }
+
+// write key (from cache) + freshly encoded value of frame ti into bank slot `slot`
+static int bank_insert(stcn_engine *e, int slot, int ti, const SlotPtrs &kf, const float *masks, long mask_stride) {
+    const Dims &d = e->d;
+    HIPCHK(hipMemcpyAsync(e->bank_k + (size_t)slot * d.hw16 * 64, kf.k16, (size_t)d.hw16 * 64 * 4, hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->bank_msq + (size_t)slot * d.hw16, kf.msq, (size_t)d.hw16 * 4, hipMemcpyDeviceToDevice, e->stream));
+    RC(encode_value(*e->model, e->work, e->stream, e->images4 + (size_t)ti * d.npix * 4, kf.f16, masks, mask_stride,
+                    bank_v_slot(e, slot), (long)e->bank_cap * d.hw16 * 512));
+    e->stats.value_enc++;
+    return STCN_OK;
+}
+
+// do_pass (inference_core.py:126-191)
+static int do_pass(stcn_engine *e, int idx, bool forward) {
+    const Dims &d = e->d;
+    const int T = e->T, k = e->k;
+    int closest;
+    if (forward) { closest = T; for (int t : e->interacted) if (t > idx && t < closest) closest = t; }
+    else { closest = -1; for (int t : e->interacted) if (t < idx && t > closest) closest = t; }
+    const int span = forward ? closest - idx - 1 : idx - closest - 1;
+    const int total_m = span / e->mem_freq + 1 + e->n_certain;
+    RC(bank_reserve(e, total_m));
+    int m_front = e->n_certain, last_ti = idx;
+    const int step = forward ? 1 : -1, end = closest - step;
+    const bool fuse = closest != T && closest != -1;
+    const long prs = (long)T * d.npix;                      // prob row stride
+    Work &w = e->work;
+    for (int ti = idx + step; ti != closest; ti += step) {
+        SlotPtrs kf;
+        RC(ensure_key(e, ti, &kf));
+        {
+            const int N = m_front * d.hw16;
+            Scope sc(&e->prof, STCN_K_MEMREAD, e->stream, 2.0 * N * d.hw16 * 64 + 2.0 * k * d.hw16 * 50 * 512);
+            memory_read_launch(e->bank_k, e->bank_msq, kf.k16, N, d.hw16, e->bank_v, (long)e->bank_cap * d.hw16 * 512, k,
+                               w.readout, (long)d.hw16 * 512, nullptr, nullptr, MemReadScratch{w.cand_v, w.cand_i}, e->stream);
+        }
+        RC(decode(*e->model, w, e->stream, w.readout, kf.f16_thin, kf.s8, kf.s4, w.agg, d.npix));
+        if (ti != end && std::abs(ti - last_ti) >= e->mem_freq) {
+            RC(bank_insert(e, m_front, ti, kf, w.agg + d.npix, d.npix));
+            ++m_front;
+            last_ti = ti;
+        }
+        float *dst = e->prob + (size_t)ti * d.npix;
+        if (fuse) {
+            // fuse_one_frame (inference_core.py:193-207): tc = closest, tr = idx
+            const float nc = (float)std::abs(closest - ti) / (float)std::abs(closest - idx);
+            const float nr = (float)std::abs(idx - ti) / (float)std::abs(closest - idx);
+            const int cs = e->n_certain - 1;               // key of the current interaction
+            {
+                Scope sc(&e->prof, STCN_K_OTHER, e->stream, 2.0 * d.hw16 * d.hw16 * 64);
+                attention_read_launch(e->bank_k + (size_t)cs * d.hw16 * 64, e->bank_msq + (size_t)cs * d.hw16, kf.k16, e->pos,
+                                      e->neg, k + 1, d.h16, d.w16, w.pooled, w.amap, w.attn, e->stream);
+            }
+            for (int o = 1; o <= k; ++o)
+                RC(fusion_logit(*e->model, w, e->stream, e->images4 + (size_t)ti * d.npix * 4, dst + (size_t)o * prs,
+                                w.agg + (size_t)o * d.npix, w.attn + (size_t)o * 2 * d.npix, nc, nr,
+                                w.flogit + (size_t)(o - 1) * d.npix));
+            Scope sc(&e->prof, STCN_K_ELEMWISE, e->stream);
+            sigmoid_aggregate_launch(w.flogit, k, d.npix, dst, prs, e->stream);
+            e->stats.fused++;
+        } else {
+            Scope sc(&e->prof, STCN_K_ELEMWISE, e->stream);
+            copy_rows_launch(w.agg, d.npix, dst, prs, k + 1, d.npix, e->stream);
+        }
+        e->stats.frames++;
+    }
+    (forward ? e->stats.bank_fwd : e->stats.bank_bwd) = m_front;
+    return STCN_OK;
+}
+
+int stcn_interact(stcn_engine *e, const float *mask_dev, int mask_channels, int idx, int scribble) {
+    if (!e || !mask_dev) { set_error("stcn_interact: null arguments"); return STCN_E_INVALID; }
+    if (idx < 0 || idx >= e->T) { set_error("stcn_interact: idx %d outside [0,%d)", idx, e->T); return STCN_E_INVALID; }
+    const int k = e->k, kk = k + 1;
+    // the reference broadcasts mask against prob[:, idx] ([k+1] rows): channels must be 1 or k+1;
+    // encode_value then needs exactly k planes (inference_core.py:222-233)
+    const int vplanes = scribble ? mask_channels - 1 : mask_channels;
+    if ((mask_channels != 1 && mask_channels != kk) || vplanes != k) {
+        set_error("stcn_interact: mask with %d channels is not valid for k=%d, scribble=%d (reference raises too)", mask_channels, k, scribble);
+        return STCN_E_INVALID;
+    }
+    HIPCHK(hipSetDevice(e->model->device));
+    const Dims &d = e->d;
+    e->stats = stcn_stats{};
+    e->prof.reset();
+    e->interacted.insert(idx);
+    {
+        Scope sc(&e->prof, STCN_K_ELEMWISE, e->stream);
+        interact_mask_launch(mask_dev, mask_channels, e->H, e->W, d.nh, d.nw, e->lw, e->lh, e->prob + (size_t)idx * d.npix,
+                             (long)e->T * d.npix, kk, e->mask_pad, e->pos, e->neg, e->stream);
+    }
+    SlotPtrs kf;
+    RC(ensure_key(e, idx, &kf));
+    RC(bank_reserve(e, e->n_certain + 1));
+    // certain memory: one slot per interaction, appended, never evicted (inference_core.py:235-240)
+    RC(bank_insert(e, e->n_certain, idx, kf, e->mask_pad + (scribble ? d.npix : 0), d.npix));
+    e->n_certain++;
+    RC(do_pass(e, idx, true));
+    RC(do_pass(e, idx, false));
+    {
+        Scope sc(&e->prof, STCN_K_ELEMWISE, e->stream);
+        argmax_launch(e->prob, kk, e->T, d.npix, e->masks, e->stream);
+    }
+    HIPCHK(hipGetLastError());
+    return STCN_OK;
+}
+
+int stcn_get_stats(const stcn_engine *e, stcn_stats *out) {
+    if (!e || !out) return STCN_E_INVALID;
+    *out = e->stats;
+    return STCN_OK;
+}
+int stcn_get_flops(const stcn_engine *e, double *flops) {
+    if (!e || !flops) return STCN_E_INVALID;
+    double t = 0;
+    for (int i = 0; i < STCN_K_COUNT; ++i) t += e->prof.flops[i];
+    *flops = t;
+    return STCN_OK;
+}
+int stcn_engine_set_profiling(stcn_engine *e, int on) {
+    if (!e) return STCN_E_INVALID;
+    e->prof.on = on != 0;
+    return STCN_OK;
+}
+int stcn_get_kernel_ms(const stcn_engine *e, float *ms, int32_t *launches) {
+    if (!e || !ms) return STCN_E_INVALID;
+    stcn_engine *me = const_cast<stcn_engine *>(e);
+    const int rc = me->prof.collect(ms);
+    if (launches) for (int i = 0; i < STCN_K_COUNT; ++i) launches[i] = e->prof.launches[i];
+    return rc;
+}
+int stcn_get_kernel_flops(const stcn_engine *e, double *flops) {
+    if (!e || !flops) return STCN_E_INVALID;
+    for (int i = 0; i < STCN_K_COUNT; ++i) flops[i] = e->prof.flops[i];
+    return STCN_OK;
+}
+
+}  // extern "C"

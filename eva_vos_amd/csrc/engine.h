@@ -1,0 +1,127 @@
+// engine.h - host-side model / workspace / per-video engine of libstcn_hip.so (internal).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "../../include/stcn_hip.h"
+#include "kernels.h"
+
+namespace stcn {
+
+void set_error(const char *fmt, ...);
+#define HIPCHK(x)                                                                          \
+    do {                                                                                   \
+        hipError_t e_ = (x);                                                               \
+        if (e_ != hipSuccess) {                                                            \
+            set_error("%s:%d %s -> %s", __FILE__, __LINE__, #x, hipGetErrorString(e_));    \
+            return STCN_E_HIP;                                                             \
+        }                                                                                  \
+    } while (0)
+
+struct ConvW {
+    float *w = nullptr, *bias = nullptr;   // device: [Cout][Kp], [Cout]
+    float bias0 = 0.f;                     // host copy of bias[0] (Cout == 1 convs)
+    int cout = 0, cin = 0, cin_p = 0, kh = 0, kw = 0, K = 0, Kp = 0;
+};
+
+struct Model {
+    int device = 0;
+    std::map<std::string, ConvW> conv;
+    CbamW cbam{};
+    bool has_fuse = false;
+    std::vector<void *> allocs;
+    const ConvW &c(const std::string &name) const;
+};
+
+struct Dims {
+    int nh, nw, h2, w2, h4, w4, h8, w8, h16, w16;
+    long npix;
+    int hw2, hw4, hw8, hw16;
+    void set(int nh_, int nw_) {
+        nh = nh_; nw = nw_;
+        h2 = nh / 2; w2 = nw / 2; h4 = nh / 4; w4 = nw / 4; h8 = nh / 8; w8 = nw / 8; h16 = nh / 16; w16 = nw / 16;
+        npix = (long)nh * nw; hw2 = h2 * w2; hw4 = h4 * w4; hw8 = h8 * w8; hw16 = h16 * w16;
+    }
+};
+
+// per-kernel-class accounting (flops always; device time when profiling is on)
+struct Prof {
+    bool on = false;
+    double flops[STCN_K_COUNT] = {0};
+    int launches[STCN_K_COUNT] = {0};
+    struct Ev { int cls; hipEvent_t a, b; };
+    std::vector<Ev> events;
+    std::vector<hipEvent_t> pool;
+    void reset();
+    void begin(int cls, hipStream_t s);
+    void end(hipStream_t s);
+    int collect(float *ms);
+    ~Prof();
+};
+
+// scratch for one in-flight frame computation (sized for nh x nw and k objects)
+struct Work {
+    Dims d{};
+    int k = 0;
+    size_t S = 0;                       // floats per big buffer
+    float *A = nullptr, *B = nullptr, *C = nullptr, *D = nullptr;
+    float *splitk = nullptr; size_t splitk_floats = 0;
+    float *cbam = nullptr;
+    float *readout = nullptr;           // [k][hw16][512]
+    float *logit4 = nullptr;            // [k][hw4]
+    float *flogit = nullptr;            // [k][npix]  fusion logits
+    float *agg = nullptr;               // [k+1][npix] aggregated output of the current frame
+    float *pooled = nullptr, *amap = nullptr, *attn = nullptr;   // attention read
+    float *cand_v = nullptr; int32_t *cand_i = nullptr;          // memory-read chunk winners
+    float *vin = nullptr;               // value-encoder packed input [k][npix][8]
+    Prof *prof = nullptr;
+    std::vector<void *> allocs;
+    int init(int nh, int nw, int k);
+    void release();
+};
+
+// ---- stages (enqueue only) -----------------------------------------------------------------
+struct KeyOut { float *k16, *msq, *f16_thin, *f16, *s8, *s4, *f8_copy, *f4_copy; };
+int run_conv(const Model &m, Work &w, hipStream_t s, const char *name, const float *x0, int c0, long bs0,
+             const float *x1, int c1, long bs1, int B, int H, int W, int stride, float *y, long y_bs,
+             const float *res, long res_bs, int relu_in, int relu_out, int force_splitk = 0);
+int encode_key(const Model &m, Work &w, hipStream_t s, const float *img4, const KeyOut &o);
+int encode_value(const Model &m, Work &w, hipStream_t s, const float *img4, const float *f16,
+                 const float *masks, long mask_stride, float *out, long out_bs);
+int decode(const Model &m, Work &w, hipStream_t s, const float *readout, const float *f16_thin,
+           const float *s8, const float *s4, float *agg, long agg_stride);
+int fusion_logit(const Model &m, Work &w, hipStream_t s, const float *img4, const float *prev,
+                 const float *curr, const float *attn2, float nc, float nr, float *logit);
+
+}  // namespace stcn
+
+struct stcn_model { stcn::Model m; };
+
+struct stcn_engine {
+    const stcn::Model *model = nullptr;
+    hipStream_t stream = nullptr;
+    int T = 0, H = 0, W = 0, k = 0, mem_freq = 5;
+    int lw = 0, uw = 0, lh = 0, uh = 0;
+    stcn::Dims d{};
+    float *images4 = nullptr;          // [T][nh][nw][4]
+    float *prob = nullptr;             // caller-owned [k+1][T][npix]
+    uint8_t *masks = nullptr;          // caller-owned [T][npix]
+    // key-feature cache
+    int n_slots = 0;
+    std::vector<int> slot_of;          // frame -> slot or -1
+    int n_cached = 0;
+    float *cache = nullptr; size_t slot_floats = 0;
+    // memory bank: rows = slots * hw16
+    int bank_cap = 0, n_certain = 0;
+    float *bank_k = nullptr, *bank_msq = nullptr, *bank_v = nullptr;
+    std::set<int> interacted;
+    float *mask_pad = nullptr, *pos = nullptr, *neg = nullptr;   // [k+1][npix] each
+    stcn::Work work;
+    stcn::Prof prof;
+    stcn_stats stats{};
+    std::vector<void *> allocs;
+};

@@ -1,0 +1,202 @@
+// hooks.cpp - stage-level C-ABI entry points used by tests/ and bench.py (see include/stcn_hip.h).
+#include <vector>
+
+#include "engine.h"
+
+using namespace stcn;
+#define RC(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+
+namespace {
+struct TmpWork {
+    Work w;
+    int rc;
+    TmpWork(int nh, int nw, int k) { rc = w.init(nh, nw, k); }
+    ~TmpWork() { (void)hipDeviceSynchronize(); w.release(); }
+};
+struct DevBuf {
+    float *p = nullptr;
+    int alloc(size_t floats) { HIPCHK(hipMalloc((void **)&p, floats * 4)); return STCN_OK; }
+    ~DevBuf() { if (p) { (void)hipDeviceSynchronize(); (void)hipFree(p); } }
+};
+}  // namespace
+
+extern "C" {
+
+int stcn_test_conv(void *stream, const float *x, const float *wgt, const float *bias, const float *res, float *y, int B,
+                   int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int flags, int splitk) {
+    if (Cin % 4 || pad != KH / 2 || KH != KW) { set_error("stcn_test_conv: Cin%%4==0, square kernel, pad=K/2 required"); return STCN_E_INVALID; }
+    hipStream_t s = (hipStream_t)stream;
+    Model m;
+    ConvW cw;
+    cw.cout = Cout; cw.cin = Cin; cw.cin_p = Cin; cw.kh = KH; cw.kw = KW;
+    cw.K = KH * KW * Cin; cw.Kp = (cw.K + 31) / 32 * 32;
+    DevBuf wpad, ws;
+    RC(wpad.alloc((size_t)Cout * cw.Kp));
+    HIPCHK(hipMemsetAsync(wpad.p, 0, (size_t)Cout * cw.Kp * 4, s));
+    HIPCHK(hipMemcpy2DAsync(wpad.p, (size_t)cw.Kp * 4, wgt, (size_t)cw.K * 4, (size_t)cw.K * 4, Cout, hipMemcpyDeviceToDevice, s));
+    cw.w = wpad.p; cw.bias = const_cast<float *>(bias);
+    m.conv["t"] = cw;
+    Work w;
+    w.splitk_floats = (size_t)16 * 1024 * 1024;
+    RC(ws.alloc(w.splitk_floats));
+    w.splitk = ws.p;
+    const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+    if (Cout == 1) {
+        if (stride != 1) { set_error("Cout==1 path is stride 1"); return STCN_E_INVALID; }
+        float b0 = 0.f;
+        if (bias) HIPCHK(hipMemcpy(&b0, bias, 4, hipMemcpyDeviceToHost));
+        conv_n1_launch(x, wpad.p, b0, y, B, H, W, Cin, KH, flags & 1, s);
+    } else {
+        RC(run_conv(m, w, s, "t", x, Cin, (long)H * W * Cin, nullptr, 0, 0, B, H, W, stride, y, 0, res, (long)OH * OW * Cout,
+                    flags & 1, (flags >> 1) & 1, splitk));
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    return STCN_OK;
+}
+
+int stcn_bench_conv(void *stream, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int splitk,
+                    int iters, float *avg_ms, double *flops_per_launch) {
+    hipStream_t s = (hipStream_t)stream;
+    (void)pad;
+    Model m;
+    ConvW cw;
+    cw.cout = Cout; cw.cin = Cin; cw.cin_p = Cin; cw.kh = KH; cw.kw = KW;
+    cw.K = KH * KW * Cin; cw.Kp = (cw.K + 31) / 32 * 32;
+    const int OH = (H + 2 * (KH / 2) - KH) / stride + 1, OW = (W + 2 * (KW / 2) - KW) / stride + 1;
+    DevBuf x, wt, b, y, ws;
+    RC(x.alloc((size_t)B * H * W * Cin)); RC(wt.alloc((size_t)Cout * cw.Kp)); RC(b.alloc(Cout));
+    RC(y.alloc((size_t)B * OH * OW * Cout));
+    // non-trivial data (zero operands raise the clock: cdna_hip_programming.md rule 25)
+    std::vector<float> h((size_t)B * H * W * Cin);
+    unsigned st = 12345u;
+    auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 32768.f - 1.f; };
+    for (auto &v : h) v = rnd();
+    HIPCHK(hipMemcpy(x.p, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    h.assign((size_t)Cout * cw.Kp, 0.f);
+    for (auto &v : h) v = rnd() * 0.05f;
+    HIPCHK(hipMemcpy(wt.p, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemsetAsync(b.p, 0, Cout * 4, s));
+    cw.w = wt.p; cw.bias = b.p;
+    m.conv["t"] = cw;
+    Work w;
+    w.splitk_floats = (size_t)32 * 1024 * 1024;
+    RC(ws.alloc(w.splitk_floats));
+    w.splitk = ws.p;
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i)
+        RC(run_conv(m, w, s, "t", x.p, Cin, (long)H * W * Cin, nullptr, 0, 0, B, H, W, stride, y.p, 0, nullptr, 0, 0, 1, splitk));
+    HIPCHK(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i)
+        RC(run_conv(m, w, s, "t", x.p, Cin, (long)H * W * Cin, nullptr, 0, 0, B, H, W, stride, y.p, 0, nullptr, 0, 0, 1, splitk));
+    HIPCHK(hipEventRecord(e1, s));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (avg_ms) *avg_ms = ms / iters;
+    if (flops_per_launch) *flops_per_launch = 2.0 * B * OH * OW * (double)Cout * KH * KW * Cin;
+    return STCN_OK;
+}
+
+static int pack_one(const float *img_chw, int nh, int nw, float *img4, hipStream_t s) {
+    pack_image_launch(img_chw, img4, nh, nw, nh, nw, 0, 0, s);
+    return STCN_OK;
+}
+
+int stcn_test_encode_key(const stcn_model *m, void *stream, const float *img, int nh, int nw, float *k16, float *f16_thin,
+                         float *f16, float *f8, float *f4) {
+    if (!m || !img || nh % 16 || nw % 16) { set_error("stcn_test_encode_key: bad arguments"); return STCN_E_INVALID; }
+    hipStream_t s = (hipStream_t)stream;
+    TmpWork t(nh, nw, 1);
+    RC(t.rc);
+    const Dims &d = t.w.d;
+    DevBuf img4, tf16, tk16, tmsq;
+    RC(img4.alloc((size_t)d.npix * 4)); RC(tf16.alloc((size_t)d.hw16 * 1024)); RC(tk16.alloc((size_t)d.hw16 * 64));
+    RC(tmsq.alloc(d.hw16));
+    RC(pack_one(img, nh, nw, img4.p, s));
+    KeyOut ko{k16 ? k16 : tk16.p, tmsq.p, f16_thin, f16 ? f16 : tf16.p, nullptr, nullptr, f8, f4};
+    RC(encode_key(m->m, t.w, s, img4.p, ko));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    return STCN_OK;
+}
+
+int stcn_test_encode_value(const stcn_model *m, void *stream, const float *img, const float *f16, const float *masks, int k,
+                           int nh, int nw, float *out) {
+    if (!m || !img || !f16 || !masks || !out || k < 1 || k > 8) { set_error("stcn_test_encode_value: bad arguments"); return STCN_E_INVALID; }
+    hipStream_t s = (hipStream_t)stream;
+    TmpWork t(nh, nw, k);
+    RC(t.rc);
+    DevBuf img4;
+    RC(img4.alloc((size_t)t.w.d.npix * 4));
+    RC(pack_one(img, nh, nw, img4.p, s));
+    RC(encode_value(m->m, t.w, s, img4.p, f16, masks, t.w.d.npix, out, 0));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    return STCN_OK;
+}
+
+int stcn_test_memory_read(void *stream, const float *mk, const float *mv, const float *qk, int N, int Q, int k,
+                          int32_t *topk_idx, float *topk_w, float *readout) {
+    if (!mk || !mv || !qk || !readout || N < 50 || Q < 1 || k < 1) { set_error("stcn_test_memory_read: bad arguments (N >= 50)"); return STCN_E_INVALID; }
+    hipStream_t s = (hipStream_t)stream;
+    DevBuf msq, cv, ci;
+    RC(msq.alloc(N)); RC(cv.alloc((size_t)16 * Q * 50)); RC(ci.alloc((size_t)16 * Q * 50));
+    rowsumsq_launch(mk, N, 64, msq.p, s);
+    memory_read_launch(mk, msq.p, qk, N, Q, mv, (long)N * 512, k, readout, (long)Q * 512, topk_idx, topk_w,
+                       MemReadScratch{cv.p, reinterpret_cast<int32_t *>(ci.p)}, s);
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    return STCN_OK;
+}
+
+int stcn_test_decode(const stcn_model *m, void *stream, const float *readout, const float *f16_thin, const float *f8,
+                     const float *f4, int k, int nh, int nw, float *logit4, float *agg) {
+    if (!m || !readout || !f16_thin || !f8 || !f4 || !agg) { set_error("stcn_test_decode: bad arguments"); return STCN_E_INVALID; }
+    hipStream_t s = (hipStream_t)stream;
+    TmpWork t(nh, nw, k);
+    RC(t.rc);
+    const Dims &d = t.w.d;
+    DevBuf s8, s4;
+    RC(s8.alloc((size_t)d.hw8 * 512)); RC(s4.alloc((size_t)d.hw4 * 256));
+    RC(run_conv(m->m, t.w, s, "decoder.up_16_8.skip_conv", f8, 512, 0, nullptr, 0, 0, 1, d.h8, d.w8, 1, s8.p, 0, nullptr, 0, 0, 0));
+    RC(run_conv(m->m, t.w, s, "decoder.up_8_4.skip_conv", f4, 256, 0, nullptr, 0, 0, 1, d.h4, d.w4, 1, s4.p, 0, nullptr, 0, 0, 0));
+    RC(decode(m->m, t.w, s, readout, f16_thin, s8.p, s4.p, agg, d.npix));
+    if (logit4) HIPCHK(hipMemcpyAsync(logit4, t.w.logit4, (size_t)k * d.hw4 * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    return STCN_OK;
+}
+
+int stcn_test_attention(void *stream, const float *mk, const float *qk, const float *pos, const float *neg, int kk, int nh,
+                        int nw, float *attn) {
+    if (!mk || !qk || !pos || !neg || !attn || kk < 1 || kk > 9) { set_error("stcn_test_attention: bad arguments"); return STCN_E_INVALID; }
+    hipStream_t s = (hipStream_t)stream;
+    const int h = nh / 16, w = nw / 16;
+    DevBuf msq, pooled, amap;
+    RC(msq.alloc(h * w)); RC(pooled.alloc((size_t)kk * 2 * h * w)); RC(amap.alloc((size_t)kk * 2 * h * w));
+    rowsumsq_launch(mk, h * w, 64, msq.p, s);
+    attention_read_launch(mk, msq.p, qk, pos, neg, kk, h, w, pooled.p, amap.p, attn, s);
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    return STCN_OK;
+}
+
+int stcn_test_fusion(const stcn_model *m, void *stream, const float *img, const float *prev, const float *curr,
+                     const float *attn, float nc, float nr, int nh, int nw, float *logit) {
+    if (!m || !img || !prev || !curr || !attn || !logit) { set_error("stcn_test_fusion: bad arguments"); return STCN_E_INVALID; }
+    hipStream_t s = (hipStream_t)stream;
+    TmpWork t(nh, nw, 1);
+    RC(t.rc);
+    DevBuf img4;
+    RC(img4.alloc((size_t)t.w.d.npix * 4));
+    RC(pack_one(img, nh, nw, img4.p, s));
+    RC(fusion_logit(m->m, t.w, s, img4.p, prev, curr, attn, nc, nr, logit));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    return STCN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,93 @@
+// kernels.h - launch wrappers of the gfx950 kernels (host-callable, enqueue on a stream).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace stcn {
+
+// ---------------------------------------------------------------- implicit-GEMM convolution
+// Activations NHWC fp32.  Input = channel-concat of up to two sources (second may be batch-broadcast).
+struct ConvP {
+    const float *x0, *x1;   // sources; x1 == nullptr when unused
+    int c0, c1;             // channels of each source (multiples of 4)
+    long bs0, bs1;          // batch strides in elements (0 = broadcast over the batch)
+    int B, H, W;            // input batch / spatial
+    int OH, OW;
+    int KH, KW, stride, pad;
+    int Cin;                // c0 + c1
+    int M, N;               // M = B*OH*OW rows, N = Cout
+    int K, Kp;              // K = KH*KW*Cin, Kp = K rounded up to 32 (weights zero-padded)
+    const float *w;         // [N][Kp], k ordered (kh, kw, cin)
+    const float *bias;      // [N] or nullptr
+    const float *res;       // residual [B][OH*OW][N] or nullptr
+    long res_bs;            // batch stride of res (0 = broadcast)
+    float *y;               // [M][N]
+    long y_bs;              // output batch stride in elements (0 = dense OH*OW*N)
+    int relu_in, relu_out;
+    int splitk;             // >= 1
+    float *partial;         // [splitk][M][N] workspace when splitk > 1
+};
+// picks the tile variant; returns the split-K it used
+int  conv_choose_splitk(const ConvP &p);
+void conv_launch(const ConvP &p, hipStream_t s);
+size_t conv_workspace_floats(const ConvP &p);
+
+// Cout == 1 convolution (decoder.pred, FusionNet.final_conv): one dot product per output pixel.
+// x [B,H,W,C] (C multiple of 4), w [KH*KW*C], y [B*H*W]; stride 1, "same" padding.
+void conv_n1_launch(const float *x, const float *w, float bias, float *y, int B, int H, int W, int C,
+                    int KH, int relu_in, hipStream_t s);
+
+// ---------------------------------------------------------------- elementwise / pooling
+void maxpool3x3s2_launch(const float *x, float *y, int B, int H, int W, int C, hipStream_t s);
+// NCHW image [3,H,W] (unpadded) -> NHWC4 padded [nh,nw,4] with zero border (pad lw, lh)
+void pack_image_launch(const float *img_chw, float *out, int H, int W, int nh, int nw, int lw, int lh,
+                       hipStream_t s);
+// value-encoder input [k,nh,nw,8] = (rgb from NHWC4 image, mask_i, sum_{j!=i} mask_j, 0,0,0)
+void pack_value_input_launch(const float *img4, const float *masks, long mask_stride, int k, int npix,
+                             float *out, hipStream_t s);
+// u[b] = skip (broadcast over b) + bilinear_up2x(x[b]); x [B,h,w,C] -> u [B,2h,2w,C]
+void upsample2x_add_launch(const float *x, const float *skip, float *u, int B, int h, int w, int C,
+                           hipStream_t s);
+// logit4 [k,h4*w4] -> bilinear x4 -> sigmoid -> aggregate_wbg -> agg [k+1][nh*nw] (row stride agg_stride)
+void up4_sigmoid_aggregate_launch(const float *logit4, int k, int h4, int w4, float *agg,
+                                  long agg_stride, hipStream_t s);
+// logits [k,npix] -> sigmoid -> aggregate -> agg rows (fusion output)
+void sigmoid_aggregate_launch(const float *logit, int k, long npix, float *agg, long agg_stride,
+                              hipStream_t s);
+// masks[t] = argmax over rows of prob [(k+1), T, npix] for all t (first max wins)
+void argmax_launch(const float *prob, int kk, int T, long npix, uint8_t *masks, hipStream_t s);
+// rows [n, C] -> msq[n] = sum_c x^2
+void rowsumsq_launch(const float *x, int n, int C, float *out, hipStream_t s);
+void fill_launch(float *p, float v, long n, hipStream_t s);
+void copy_rows_launch(const float *src, long src_stride, float *dst, long dst_stride, int rows, long n,
+                      hipStream_t s);
+// interaction mask handling (inference_core.py:220-226): pads mask [mc,H,W] into [mc,nh,nw] planes,
+// writes pos/neg = clamp(+-(mask - prob[:,idx])) for all kk rows, then prob[:,idx] = mask (broadcast)
+void interact_mask_launch(const float *mask, int mc, int H, int W, int nh, int nw, int lw, int lh,
+                          float *prob_idx, long prob_row_stride, int kk, float *padded, float *pos,
+                          float *neg, hipStream_t s);
+
+// ---------------------------------------------------------------- CBAM (cbam.py:21-77)
+struct CbamW { const float *w1, *b1, *w2, *b2, *wsp; float bsp; };  // 512->32->512 MLP, 7x7 [2] conv
+// x [B,hw,512] -> out = x + CBAM(x); scratch >= B*(1024 + 512 + 3*hw) floats
+void cbam_launch(const float *x, float *out, int B, int h, int w, const CbamW &cw, float *scratch,
+                 hipStream_t s);
+
+// ---------------------------------------------------------------- space-time memory read
+struct MemReadScratch { float *cand_v; int32_t *cand_i; };   // [NC][Q][50] each
+int  memread_num_chunks(int N);
+// mk [N,64], msq [N], qk [Q,64]; mv [k][N][512] with object stride mv_os; readout [k][Q][512] with
+// row stride ro_ld (floats) and object stride ro_os.  topk_idx/topk_w optional outputs [Q,50].
+void memory_read_launch(const float *mk, const float *msq, const float *qk, int N, int Q,
+                        const float *mv, long mv_os, int k, float *readout, long ro_os,
+                        int32_t *topk_idx, float *topk_w, MemReadScratch scr, hipStream_t s);
+// fusion attention read: mk,qk [hw,64]; pos,neg [kk][16h*16w planes] -> attn [kk][2][nh*nw]
+void attention_read_launch(const float *mk, const float *msq, const float *qk, const float *pos,
+                           const float *neg, int kk, int h, int w, float *pooled, float *amap,
+                           float *attn, hipStream_t s);
+// fusion input [nh*nw,12] = (rgb, prev, curr, attn_pos, attn_neg, nc, nr, 0,0,0)
+void pack_fusion_input_launch(const float *img4, const float *prev, const float *curr,
+                              const float *attn2, float nc, float nr, long npix, float *out,
+                              hipStream_t s);
+
+}  // namespace stcn

@@ -1,0 +1,158 @@
+"""Drop-in ``InferenceCore`` over the HIP engine (libstcn_hip.so).
+
+Mirrors the public surface of the reference class ``mivos/inference_core.py:16-259``:
+``InferenceCore(prop_net, fuse_net, images, num_objects, mem_profile=0, mem_freq=5, device='cuda')``,
+``.interact(mask, idx, scribble=False) -> np.uint8[t,h,w]`` and the attributes its callers read
+(``prob``, ``pad``, ``t``, ``masks``, ``np_masks``, ``k``, ``h``, ``w``, ``nh``, ``nw``, ``kh``,
+``kw``; ``get_image_buffered``; ``copy.deepcopy``).  This file only marshals arguments: padding,
+feature caching, the memory bank, both propagation passes, fusion and the argmax all run inside the
+engine on the current HIP stream.  PyTorch is used for device memory and stream ordering only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import weakref
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_MODEL_CACHE: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+
+
+class _Model:
+    """Owns one ``stcn_model`` handle (BN-folded, repacked weights on one device)."""
+
+    def __init__(self, prop_net, fuse_net, device_index: int):
+        lib = _lib.lib()
+        keep = []
+
+        def descs(module):
+            sd = {k: v for k, v in module.state_dict().items() if v.is_floating_point()}
+            arr = (_lib.WeightDesc * len(sd))()
+            for i, (name, t) in enumerate(sd.items()):
+                t = t.detach().to("cpu", torch.float32).contiguous()
+                keep.append(t)
+                arr[i].name = name.encode()
+                arr[i].data = t.data_ptr()
+                arr[i].ndim = t.dim()
+                for d in range(t.dim()):
+                    arr[i].shape[d] = t.shape[d]
+            return arr, len(sd)
+
+        p, n_p = descs(prop_net)
+        f, n_f = descs(fuse_net) if fuse_net is not None else (None, 0)
+        h = C.c_void_p()
+        _lib.check(lib.stcn_model_create(device_index, p, n_p, f, n_f, C.byref(h)), "stcn_model_create")
+        self.handle = h
+        self._finalizer = weakref.finalize(self, lib.stcn_model_destroy, h)
+
+
+def _model_for(prop_net, fuse_net, device_index: int) -> _Model:
+    per_net = _MODEL_CACHE.setdefault(prop_net, {})
+    key = (id(fuse_net), device_index)
+    if key not in per_net:
+        per_net[key] = _Model(prop_net, fuse_net, device_index)
+    return per_net[key]
+
+
+def _pad16(n: int):
+    d = (-n) % 16
+    lo = d // 2
+    return lo, d - lo
+
+
+class InferenceCore:
+    def __init__(self, prop_net, fuse_net, images, num_objects, mem_profile=0, mem_freq=5, device="cuda"):
+        if not torch.cuda.is_available():
+            raise RuntimeError("eva_vos_amd.InferenceCore needs a HIP device (there is no CPU fallback); "
+                               "the CPU oracle lives in oracle/ and is test infrastructure only")
+        self.device = torch.device(device if device != "cuda" else f"cuda:{torch.cuda.current_device()}")
+        if self.device.type != "cuda":
+            raise RuntimeError(f"device {device!r}: the HIP engine only runs on a GPU")
+        self.prop_net, self.fuse_net = prop_net, fuse_net
+        self.mem_profile, self.mem_freq = mem_profile, mem_freq   # mem_profile: results never depend on it
+        self.data_dev = self.result_dev = self.device
+        self.k = int(num_objects)
+        t = images.shape[1]
+        h, w = images.shape[-2:]
+        self.t, self.h, self.w = int(t), int(h), int(w)
+        (lh, uh), (lw, uw) = _pad16(self.h), _pad16(self.w)
+        self.pad = (lw, uw, lh, uh)
+        self.nh, self.nw = self.h + lh + uh, self.w + lw + uw
+        self.kh, self.kw = self.nh // 16, self.nw // 16
+        self._model = _model_for(prop_net, fuse_net, self.device.index or 0)
+        with torch.cuda.device(self.device):
+            self._stream = torch.cuda.current_stream()
+            imgs = images.detach().to(self.device, torch.float32).contiguous()
+            self.prob = torch.empty((self.k + 1, self.t, 1, self.nh, self.nw), dtype=torch.float32, device=self.device)
+            self.masks = torch.empty((self.t, 1, self.nh, self.nw), dtype=torch.uint8, device=self.device)
+            self.np_masks = np.zeros((self.t, self.h, self.w), dtype=np.uint8)
+            h_ = C.c_void_p()
+            _lib.check(_lib.lib().stcn_engine_create(
+                self._model.handle, self.t, self.h, self.w, self.k, int(mem_freq), self._stream.cuda_stream,
+                imgs.data_ptr(), self.prob.data_ptr(), self.masks.data_ptr(), C.byref(h_)), "stcn_engine_create")
+        self._images_unpadded = imgs
+        self._engine = h_
+        self._finalizer = weakref.finalize(self, _lib.lib().stcn_engine_destroy, h_)
+        self.interacted = set()
+
+    # ------------------------------------------------------------------------------------------
+    def interact(self, mask, idx, scribble=False):
+        """Interact -> propagate -> fuse; returns np.uint8 [t,h,w] (reference inference_core.py:209-259)."""
+        idx = int(idx)
+        mask = mask.detach().to(self.device, torch.float32).contiguous()
+        if mask.dim() != 4 or mask.shape[1] != 1 or tuple(mask.shape[-2:]) != (self.h, self.w):
+            raise RuntimeError(f"mask must be [C,1,{self.h},{self.w}], got {tuple(mask.shape)}")
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().stcn_interact(self._engine, mask.data_ptr(), int(mask.shape[0]), idx,
+                                                1 if scribble else 0), "stcn_interact")
+            self.interacted.add(idx)
+            lw, uw, lh, uh = self.pad
+            out = self.masks[:, 0, lh:self.nh - uh, lw:self.nw - uw]
+            self.np_masks = out.cpu().numpy().astype(np.uint8)     # D2H sync, as the reference's .cpu()
+        return self.np_masks
+
+    def get_image_buffered(self, idx):
+        lw, uw, lh, uh = self.pad
+        return torch.nn.functional.pad(self._images_unpadded[:, idx], (lw, uw, lh, uh))
+
+    @property
+    def images(self):
+        lw, uw, lh, uh = self.pad
+        return torch.nn.functional.pad(self._images_unpadded, (lw, uw, lh, uh))
+
+    def stats(self) -> dict:
+        s = _lib.Stats()
+        _lib.check(_lib.lib().stcn_get_stats(self._engine, C.byref(s)))
+        return {n: getattr(s, n) for n, _ in _lib.Stats._fields_}
+
+    def set_profiling(self, on: bool) -> None:
+        _lib.check(_lib.lib().stcn_engine_set_profiling(self._engine, 1 if on else 0))
+
+    def kernel_profile(self) -> dict:
+        """Per-kernel-class device ms / launches / algorithmic FLOP of the last interact()."""
+        n = len(_lib.K_CLASSES)
+        ms, ln, fl = (C.c_float * n)(), (C.c_int32 * n)(), (C.c_double * n)()
+        _lib.check(_lib.lib().stcn_get_kernel_ms(self._engine, ms, ln))
+        _lib.check(_lib.lib().stcn_get_kernel_flops(self._engine, fl))
+        return {c: dict(ms=ms[i], launches=ln[i], flops=fl[i]) for i, c in enumerate(_lib.K_CLASSES)}
+
+    def __deepcopy__(self, memo):
+        new = object.__new__(InferenceCore)
+        for k, v in self.__dict__.items():
+            if k in ("_engine", "_finalizer", "prob", "masks", "np_masks", "interacted"):
+                continue
+            new.__dict__[k] = v                                   # nets, model handle, images: shared (read-only)
+        with torch.cuda.device(self.device):
+            torch.cuda.current_stream().synchronize()
+            new.prob, new.masks = self.prob.clone(), self.masks.clone()
+            new.np_masks, new.interacted = self.np_masks.copy(), set(self.interacted)
+            new._stream = torch.cuda.current_stream()
+            h_ = C.c_void_p()
+            _lib.check(_lib.lib().stcn_engine_clone(self._engine, new.prob.data_ptr(), new.masks.data_ptr(),
+                                                    new._stream.cuda_stream, C.byref(h_)), "stcn_engine_clone")
+        new._engine = h_
+        new._finalizer = weakref.finalize(new, _lib.lib().stcn_engine_destroy, h_)
+        return new

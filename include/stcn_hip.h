@@ -1,0 +1,160 @@
+/*
+ * stcn_hip.h - C ABI of libstcn_hip.so, the MI355X (gfx950) STCN mask-propagation engine.
+ *
+ * The reference (thanosDelatolas/eva-vos) has no FFI: its boundary for this path is the Python
+ * class mivos.inference_core.InferenceCore.  Every entry point below cites the reference
+ * interface it replaces (paths under /root/reference).  The only caller is the ctypes shim
+ * eva_vos_amd/inference_core.py (re-exported as mivos/inference_core.py); see INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C: opaque handles, raw pointers, sizes; no torch / C++ types cross the boundary.
+ *   - every function returns 0 on success or a negative STCN_E_* code; stcn_last_error() gives a
+ *     thread-local message.  No exception crosses the ABI.
+ *   - "dev" pointers are HIP device pointers on the engine's device; the caller owns them and
+ *     keeps them alive for the lifetime stated per function.
+ *   - an engine is NOT thread-safe; one engine <-> one HIP stream <-> one video.  Distinct engines
+ *     may be driven concurrently from distinct host threads.
+ *   - all activations are fp32 (the reference computes in fp32 throughout).
+ */
+#ifndef STCN_HIP_H
+#define STCN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STCN_OK            0
+#define STCN_E_INVALID    -1   /* bad argument / shape */
+#define STCN_E_MISSING    -2   /* a required weight tensor is absent */
+#define STCN_E_HIP        -3   /* HIP runtime error */
+#define STCN_E_STATE      -4   /* call not valid in the current engine state */
+
+typedef struct stcn_model  stcn_model;   /* folded + repacked weights, read-only, shareable */
+typedef struct stcn_engine stcn_engine;  /* per-video state */
+
+/* One named fp32 tensor of a state_dict (host memory, C-contiguous).
+ * Replaces: torch `state_dict()` of PropagationNetwork / FusionNet handed to
+ * InferenceCore.__init__ as live nn.Modules (mivos/inference_core.py:34-38;
+ * eval_annotation_method.py:58-64). */
+typedef struct {
+    const char  *name;      /* e.g. "key_encoder.layer3.0.conv2.weight" */
+    const float *data;      /* host pointer, fp32 */
+    int32_t      ndim;      /* 1..4 */
+    int64_t      shape[4];
+} stcn_weight_desc;
+
+const char *stcn_last_error(void);
+const char *stcn_version(void);
+
+/* Build a model on HIP device `device`: folds every eval-mode BatchNorm into its convolution,
+ * repacks weights to the engine's [Cout][kh][kw][Cin] layout and uploads them.
+ * `prop` must hold the 405-tensor PropagationNetwork dict (int64 num_batches_tracked entries may be
+ * omitted); `fuse` the 12-tensor FusionNet dict or NULL/0 (then fusion rounds fail with STCN_E_STATE).
+ * Replaces: prop_net.to(device) / fuse_net.to(device) (inference_core.py:36-38). */
+int stcn_model_create(int device,
+                      const stcn_weight_desc *prop, int n_prop,
+                      const stcn_weight_desc *fuse, int n_fuse,
+                      stcn_model **out);
+int stcn_model_destroy(stcn_model *m);
+
+/* Create the per-video engine.
+ *   images_dev : fp32 [1,T,3,H,W] (NCHW, normalized, unpadded), read once during this call.
+ *   prob_dev   : fp32 [k+1,T,1,nh,nw] owned by the caller (a torch tensor in the shim); the engine
+ *                initialises it (bg row 1e-7, others 0) and writes into it on every interact().
+ *   masks_dev  : uint8 [T,1,nh,nw] owned by the caller; per-frame argmax written by interact().
+ *   nh, nw     : H, W rounded up to multiples of 16 (symmetric zero pad, tensor_util.py:62-80).
+ *   stream     : hipStream_t (as void*) all engine work is enqueued on; NULL = default stream.
+ * Replaces: InferenceCore.__init__ (inference_core.py:34-99) with mem_profile=0. */
+int stcn_engine_create(const stcn_model *m, int T, int H, int W, int k, int mem_freq,
+                       void *stream, const float *images_dev, float *prob_dev, uint8_t *masks_dev,
+                       stcn_engine **out);
+int stcn_engine_destroy(stcn_engine *e);
+
+/* Deep copy of all engine state (certain memory, key cache, interaction set).  The clone writes to
+ * the caller-provided prob/masks buffers, which the caller must have filled with a copy of the
+ * source's.  Replaces: copy.deepcopy(processor) (interactions/policies.py:103-104). */
+int stcn_engine_clone(const stcn_engine *src, float *prob_dev, uint8_t *masks_dev, void *stream,
+                      stcn_engine **out);
+
+/* Interact -> propagate both ways -> fuse -> per-frame argmax.
+ *   mask_dev      : fp32 [mask_channels,1,H,W] (unpadded).  mask_channels is k (no bg row; only
+ *                   valid for k==1, scribble==0) or k+1 (bg first; requires scribble!=0), exactly as
+ *                   the reference accepts (inference_core.py:220-233).
+ *   Enqueues on the engine stream and returns without synchronising; prob_dev / masks_dev are
+ *   complete once the stream has drained.
+ * Replaces: InferenceCore.interact (inference_core.py:209-259) incl. do_pass (:126-191) and
+ * fuse_one_frame (:193-207). */
+int stcn_interact(stcn_engine *e, const float *mask_dev, int mask_channels, int idx, int scribble);
+
+/* Counters of the last interact(): frames visited by the propagation loops, key-encoder misses,
+ * value encodes, fused frames, final bank sizes of the forward / backward pass. */
+typedef struct {
+    int32_t frames, key_miss, value_enc, fused, bank_fwd, bank_bwd;
+} stcn_stats;
+int stcn_get_stats(const stcn_engine *e, stcn_stats *out);
+
+/* Algorithmic work of the last interact() in FLOP (2 x MAC of every conv / GEMM issued). */
+int stcn_get_flops(const stcn_engine *e, double *flops);
+
+/* ---- stage-level hooks (used by tests/ and bench.py only; all pointers are device fp32) --------
+ * Layouts are the engine's internal ones: activations NHWC, i.e. [rows = h*w][channels]. */
+
+/* Generic convolution through the implicit-GEMM kernel (what every nn.Conv2d of the path lowers to:
+ * modules.py / mod_resnet.py / prop_net.py convs).  x: [B,H,W,Cin] (Cin multiple of 4),
+ * w: [Cout,KH,KW,Cin], bias: [Cout], res: [B,OH,OW,Cout] or NULL, y: [B,OH,OW,Cout].
+ * flags: bit0 relu on input, bit1 relu on output.  splitk<=0 lets the engine choose. */
+int stcn_test_conv(void *stream, const float *x, const float *w, const float *bias, const float *res,
+                   float *y, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
+                   int pad, int flags, int splitk);
+
+/* encode_key of one frame (prop_net.py:172-177).  img: [1,3,nh,nw] NCHW padded.  Outputs (NHWC):
+ * k16 [hw16,64], f16_thin [hw16,512], f16 [hw16,1024], f8 [hw8,512], f4 [hw4,256]; any may be NULL. */
+int stcn_test_encode_key(const stcn_model *m, void *stream, const float *img, int nh, int nw,
+                         float *k16, float *f16_thin, float *f16, float *f8, float *f4);
+
+/* encode_value (prop_net.py:153-170).  masks: [k,nh*nw] planes; f16 NHWC; out [k,hw16,512]. */
+int stcn_test_encode_value(const stcn_model *m, void *stream, const float *img, const float *f16,
+                           const float *masks, int k, int nh, int nw, float *out);
+
+/* Space-time memory read (prop_net.py:80-115 with the top-50 softmax of :53-60).
+ * mk [N,64], mv [k,N,512], qk [Q,64] -> topk_idx [Q,50] (int32), topk_w [Q,50], readout [k,Q,512]. */
+int stcn_test_memory_read(void *stream, const float *mk, const float *mv, const float *qk,
+                          int N, int Q, int k, int32_t *topk_idx, float *topk_w, float *readout);
+
+/* Decoder + sigmoid + soft aggregation (prop_net.py:13-30,189-192; aggregate.py:22-37).
+ * readout [k,hw16,512], f16_thin/f8/f4 NHWC -> logit4 [k,hw4] (may be NULL), agg [k+1,nh*nw]. */
+int stcn_test_decode(const stcn_model *m, void *stream, const float *readout, const float *f16_thin,
+                     const float *f8, const float *f4, int k, int nh, int nw, float *logit4, float *agg);
+
+/* Attention read of fusion (prop_net.py:117-138,198-211).  mk,qk [hw16,64]; pos,neg [kk,nh*nw]
+ * -> attn [kk,2,nh*nw]. */
+int stcn_test_attention(void *stream, const float *mk, const float *qk, const float *pos,
+                        const float *neg, int kk, int nh, int nw, float *attn);
+
+/* FusionNet logit for one object (fusion_net.py:32-50).  img [1,3,nh,nw] NCHW; prev,curr [nh*nw];
+ * attn [2,nh*nw] -> logit [nh*nw]. */
+int stcn_test_fusion(const stcn_model *m, void *stream, const float *img, const float *prev,
+                     const float *curr, const float *attn, float nc, float nr, int nh, int nw,
+                     float *logit);
+
+/* Time `iters` launches of the dominant kernel (implicit-GEMM conv) on `stream` with HIP events;
+ * returns average milliseconds per launch.  Used by bench.py for the roofline object. */
+int stcn_bench_conv(void *stream, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
+                    int pad, int splitk, int iters, float *avg_ms, double *flops_per_launch);
+
+/* Per-kernel-class time of the last interact() measured with HIP events on the engine stream
+ * (enabled by stcn_engine_set_profiling(e,1); adds a few % overhead).  ms[] indexed by STCN_K_*. */
+enum { STCN_K_CONV = 0, STCN_K_CONV_REDUCE, STCN_K_MEMREAD, STCN_K_ELEMWISE, STCN_K_CONV_N1,
+       STCN_K_OTHER, STCN_K_COUNT };
+int stcn_engine_set_profiling(stcn_engine *e, int on);
+int stcn_get_kernel_ms(const stcn_engine *e, float *ms /*[STCN_K_COUNT]*/, int32_t *launches /*[STCN_K_COUNT]*/);
+/* Algorithmic FLOP (2 x MAC) issued per kernel class by the last interact(). */
+int stcn_get_kernel_flops(const stcn_engine *e, double *flops /*[STCN_K_COUNT]*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STCN_HIP_H */

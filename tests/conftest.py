@@ -1,0 +1,63 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+torch.set_grad_enabled(False)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def weights():
+    """(prop_state_dict, fuse_state_dict) from the frozen synthetic recipe (seed 0)."""
+    from eva_vos_amd import synth
+    from eva_vos_amd.params import FusionNet, PropagationNetwork
+    return synth.recipe_state_dict(PropagationNetwork()), synth.recipe_state_dict(FusionNet())
+
+
+@pytest.fixture(scope="session")
+def nets(weights):
+    """Parameter containers loaded with the recipe (what a user would pass to InferenceCore)."""
+    from eva_vos_amd.params import FusionNet, PropagationNetwork
+    p, f = PropagationNetwork(), FusionNet()
+    p.load_state_dict(weights[0], strict=True)
+    f.load_state_dict(weights[1], strict=True)
+    return p.eval(), f.eval()
+
+
+def load_golden(tag):
+    return dict(np.load(os.path.join(GOLD, f"{tag}.npz")))
+
+
+def sample_of(t, stride):
+    return t.detach().float().cpu().numpy().reshape(-1)[::stride]
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def iou(a, b):
+    a, b = np.asarray(a).astype(bool), np.asarray(b).astype(bool)
+    u = (a | b).sum()
+    return 1.0 if u == 0 else float((a & b).sum() / u)

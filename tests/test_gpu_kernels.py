@@ -1,0 +1,125 @@
+"""GPU: each hand-written HIP kernel family against a CPU reference of the same op (through the C ABI)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_util import call, dev, nhwc, ptr, stream
+from oracle import stcn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+#        B   H    W   Cin  Cout K  s  flags splitk
+CONVS = [
+    (1, 30, 54, 1024, 256, 1, 1, 0, 0),     # key encoder 1x1
+    (1, 30, 54, 256, 256, 3, 1, 2, 0),      # 3x3 + relu out
+    (1, 28, 44, 128, 128, 3, 2, 0, 1),      # stride 2, no split
+    (1, 30, 54, 512, 64, 3, 1, 0, 4),       # forced split-K 4
+    (2, 17, 23, 64, 128, 3, 1, 3, 0),       # ragged M, batch 2, relu in+out, residual
+    (1, 64, 80, 4, 64, 7, 2, 2, 0),         # key stem (Cin padded 3->4)
+    (2, 48, 64, 8, 64, 7, 2, 2, 0),         # value stem (Cin padded 5->8), batch 2
+    (1, 40, 56, 12, 32, 3, 1, 2, 0),        # fusion conv1 (9->12 channels), narrow tile
+    (1, 40, 56, 32, 32, 3, 1, 0, 0),        # fusion 32->32 + residual
+    (1, 9, 7, 64, 64, 1, 1, 0, 0),          # tiny
+    (1, 15, 27, 1280, 512, 3, 1, 1, 0),     # fuser-like big K, relu in, auto split
+    (1, 30, 54, 256, 1, 3, 1, 1, 0),        # decoder.pred (Cout 1), relu in
+    (1, 40, 56, 32, 1, 3, 1, 0, 0),         # fusion final_conv (Cout 1)
+]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,K,s,flags,splitk", CONVS)
+def test_conv_matches_fp64_reference(B, H, W, Cin, Cout, K, s, flags, splitk):
+    g = torch.Generator().manual_seed(Cin * 131 + Cout * 7 + K)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, K, K, generator=g) * (2.0 / (Cin * K * K)) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    OH, OW = (H + 2 * (K // 2) - K) // s + 1, (W + 2 * (K // 2) - K) // s + 1
+    use_res = Cout > 1 and (B == 2 or (Cin == 32 and Cout == 32))
+    res = torch.randn(B, Cout, OH, OW, generator=g) if use_res else None
+    xin = F.relu(x) if flags & 1 else x
+    ref = F.conv2d(xin.double(), w.double(), b.double(), stride=s, padding=K // 2)
+    if res is not None:
+        ref = ref + res.double()
+    if flags & 2:
+        ref = F.relu(ref)
+    y = torch.empty(B, OH, OW, Cout, device="cuda")
+    call("stcn_test_conv", stream(), ptr(nhwc(x)), ptr(dev(w.permute(0, 2, 3, 1))), ptr(dev(b)),
+         ptr(nhwc(res)) if res is not None else None, ptr(y), B, H, W, Cin, Cout, K, K, s, K // 2, flags, splitk)
+    got = y.permute(0, 3, 1, 2).cpu().double()
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 2e-5, err          # fp32 accumulation vs fp64
+
+
+def _memread(mk, mv, qk):
+    N, Q, k = mk.shape[0], qk.shape[0], mv.shape[0]
+    idx = torch.empty(Q, 50, dtype=torch.int32, device="cuda")
+    w = torch.empty(Q, 50, device="cuda")
+    ro = torch.empty(k, Q, 512, device="cuda")
+    call("stcn_test_memory_read", stream(), ptr(dev(mk)), ptr(dev(mv)), ptr(dev(qk)), N, Q, k, ptr(idx), ptr(w), ptr(ro))
+    return idx.cpu().long(), w.cpu(), ro.cpu()
+
+
+def _dense(idx, w, N):
+    d = torch.zeros(idx.shape[0], N)
+    d.scatter_(1, idx, w)
+    return d
+
+
+@pytest.mark.parametrize("N,Q,k,scale", [(160, 80, 1, 1.0), (1620, 333, 2, 1.0), (5000, 200, 3, 0.5),
+                                         (20 * 1620, 97, 1, 1.0), (50, 16, 1, 1.0)])
+def test_memory_read_matches_oracle(N, Q, k, scale):
+    g = torch.Generator().manual_seed(N + Q)
+    mk = torch.randn(N, 64, generator=g) * scale
+    qk = torch.randn(Q, 64, generator=g) * scale
+    mv = torch.randn(k, N, 512, generator=g)
+    oi, ow, oro = O.memory_read(mk, mv, qk)
+    gi, gw, gro = _memread(mk, mv, qk)
+    assert (gi >= 0).all() and (gi < N).all()
+    assert all(len(set(r.tolist())) == 50 for r in gi), "duplicate rows selected"
+    assert (_dense(gi, gw, N) - _dense(oi, ow, N)).abs().max() < 2e-5
+    assert torch.allclose(gw.sum(1), torch.ones(Q), atol=1e-5)
+    assert (gro - oro).abs().max() / oro.abs().max() < 2e-5
+
+
+def test_memory_read_rising_scores_forces_many_selects():
+    """Scores increase with the row index, so every tile beats the running threshold (worst case for
+    the streaming top-k: a select every tile)."""
+    N, Q = 4000, 48
+    u = torch.randn(64, generator=torch.Generator().manual_seed(3))
+    u = u / u.norm() * 3.0
+    a = torch.linspace(0.0, 0.9, N)[:, None]
+    mk = a * u[None, :] + 1e-3 * torch.randn(N, 64, generator=torch.Generator().manual_seed(4))
+    qk = u[None, :].repeat(Q, 1) + 0.05 * torch.randn(Q, 64, generator=torch.Generator().manual_seed(5))
+    mv = torch.randn(1, N, 512, generator=torch.Generator().manual_seed(6))
+    oi, ow, oro = O.memory_read(mk, mv, qk)
+    gi, gw, gro = _memread(mk, mv, qk)
+    assert (_dense(gi, gw, N) - _dense(oi, ow, N)).abs().max() < 5e-5
+    assert (gro - oro).abs().max() / oro.abs().max() < 5e-5
+
+
+def test_memory_read_handles_exact_ties():
+    """Duplicated memory rows give exactly tied scores at the cut; any tie-break is valid, the weights
+    of the kept set and the readout must still agree."""
+    N, Q = 640, 32
+    g = torch.Generator().manual_seed(9)
+    base = torch.randn(N // 4, 64, generator=g)
+    mk = base.repeat(4, 1)                       # every row 4 times -> ties everywhere
+    mvb = torch.randn(1, N // 4, 512, generator=g)
+    mv = mvb.repeat(1, 4, 1)                     # tied rows carry identical values
+    qk = torch.randn(Q, 64, generator=g)
+    _, _, oro = O.memory_read(mk, mv, qk)
+    gi, gw, gro = _memread(mk, mv, qk)
+    assert all(len(set(r.tolist())) == 50 for r in gi)
+    assert (gro - oro).abs().max() / oro.abs().max() < 2e-5
+
+
+def test_attention_read_matches_oracle():
+    h, w, kk = 8, 10, 4
+    g = torch.Generator().manual_seed(11)
+    mk, qk = torch.randn(h * w, 64, generator=g), torch.randn(h * w, 64, generator=g)
+    pos = torch.rand(kk, 1, 16 * h, 16 * w, generator=g)
+    neg = torch.rand(kk, 1, 16 * h, 16 * w, generator=g)
+    ref = O.attention_read(mk, qk, pos, neg)
+    out = torch.empty(kk, 2, 16 * h, 16 * w, device="cuda")
+    call("stcn_test_attention", stream(), ptr(dev(mk)), ptr(dev(qk)), ptr(dev(pos)), ptr(dev(neg)), kk, 16 * h, 16 * w, ptr(out))
+    assert (out.cpu() - ref).abs().max() < 1e-5
