@@ -8,6 +8,8 @@ from eva_vos_amd.inference_core import _model_for
 
 
 def dev(t):
+    if t.dtype in (torch.int32, torch.uint8):
+        return t.detach().to("cuda").contiguous()
     return t.detach().to("cuda", torch.float32).contiguous()
 
 
@@ -32,5 +34,11 @@ def model_handle(nets):
 
 
 def call(name, *args):
-    _lib.check(getattr(_lib.lib(), name)(*args), name)
+    """Call a C-ABI entry point.  Tensor arguments are passed as tensors (kept alive for the whole call
+    and converted to device pointers here); None -> NULL."""
+    keep = [dev(a) if isinstance(a, torch.Tensor) and (a.device.type != "cuda" or not a.is_contiguous()) else a
+            for a in args]
+    conv = [C.c_void_p(a.data_ptr()) if isinstance(a, torch.Tensor) else a for a in keep]
+    _lib.check(getattr(_lib.lib(), name)(*conv), name)
     torch.cuda.synchronize()
+    del keep

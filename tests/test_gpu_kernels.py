@@ -4,7 +4,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from gpu_util import call, dev, nhwc, ptr, stream
+from gpu_util import call, dev, nhwc, stream
 from oracle import stcn_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -43,8 +43,8 @@ def test_conv_matches_fp64_reference(B, H, W, Cin, Cout, K, s, flags, splitk):
     if flags & 2:
         ref = F.relu(ref)
     y = torch.empty(B, OH, OW, Cout, device="cuda")
-    call("stcn_test_conv", stream(), ptr(nhwc(x)), ptr(dev(w.permute(0, 2, 3, 1))), ptr(dev(b)),
-         ptr(nhwc(res)) if res is not None else None, ptr(y), B, H, W, Cin, Cout, K, K, s, K // 2, flags, splitk)
+    call("stcn_test_conv", stream(), nhwc(x), dev(w.permute(0, 2, 3, 1)), dev(b),
+         None if res is None else nhwc(res), y, B, H, W, Cin, Cout, K, K, s, K // 2, flags, splitk)
     got = y.permute(0, 3, 1, 2).cpu().double()
     err = (got - ref).abs().max().item() / ref.abs().max().item()
     assert err < 2e-5, err          # fp32 accumulation vs fp64
@@ -55,7 +55,7 @@ def _memread(mk, mv, qk):
     idx = torch.empty(Q, 50, dtype=torch.int32, device="cuda")
     w = torch.empty(Q, 50, device="cuda")
     ro = torch.empty(k, Q, 512, device="cuda")
-    call("stcn_test_memory_read", stream(), ptr(dev(mk)), ptr(dev(mv)), ptr(dev(qk)), N, Q, k, ptr(idx), ptr(w), ptr(ro))
+    call("stcn_test_memory_read", stream(), dev(mk), dev(mv), dev(qk), N, Q, k, idx, w, ro)
     return idx.cpu().long(), w.cpu(), ro.cpu()
 
 
@@ -121,5 +121,5 @@ def test_attention_read_matches_oracle():
     neg = torch.rand(kk, 1, 16 * h, 16 * w, generator=g)
     ref = O.attention_read(mk, qk, pos, neg)
     out = torch.empty(kk, 2, 16 * h, 16 * w, device="cuda")
-    call("stcn_test_attention", stream(), ptr(dev(mk)), ptr(dev(qk)), ptr(dev(pos)), ptr(dev(neg)), kk, 16 * h, 16 * w, ptr(out))
+    call("stcn_test_attention", stream(), dev(mk), dev(qk), dev(pos), dev(neg), kk, 16 * h, 16 * w, out)
     assert (out.cpu() - ref).abs().max() < 1e-5

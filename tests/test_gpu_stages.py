@@ -6,7 +6,7 @@ import torch
 
 from conftest import load_golden, rel_err, sample_of
 from eva_vos_amd import synth
-from gpu_util import call, dev, model_handle, ptr, rows_to_nchw, stream
+from gpu_util import call, dev, model_handle, rows_to_nchw, stream
 from oracle import stcn_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -19,8 +19,8 @@ def gpu_encode_key(nets, img):
     o = dict(k16=torch.empty(1, h * w, 64, device="cuda"), f16_thin=torch.empty(1, h * w, 512, device="cuda"),
              f16=torch.empty(1, h * w, 1024, device="cuda"), f8=torch.empty(1, 4 * h * w, 512, device="cuda"),
              f4=torch.empty(1, 16 * h * w, 256, device="cuda"))
-    call("stcn_test_encode_key", model_handle(nets), stream(), ptr(dev(img)), nh, nw, ptr(o["k16"]), ptr(o["f16_thin"]),
-         ptr(o["f16"]), ptr(o["f8"]), ptr(o["f4"]))
+    call("stcn_test_encode_key", model_handle(nets), stream(), dev(img), nh, nw, o["k16"], o["f16_thin"],
+         o["f16"], o["f8"], o["f4"])
     return o
 
 
@@ -51,8 +51,8 @@ def test_stage_graphs(tag, nets, weights):
     # ---- encode_value
     ov = O.encode_value(fw, imgs[:, 0], okf[2], m0)
     gv = torch.empty(k, h * w, 512, device="cuda")
-    call("stcn_test_encode_value", model_handle(nets), stream(), ptr(dev(imgs[:, 0])), ptr(gkf_dev["f16"]),
-         ptr(dev(m0.reshape(k, -1))), k, nh, nw, ptr(gv))
+    call("stcn_test_encode_value", model_handle(nets), stream(), dev(imgs[:, 0]), gkf_dev["f16"],
+         dev(m0.reshape(k, -1)), k, nh, nw, gv)
     gv_n = rows_to_nchw(gv, h, w)
     assert rel_err(gv_n.numpy(), ov.numpy()) < 3e-5
     assert rel_err(sample_of(gv_n, 11), g[f"{tag}.value0.sample"]) < 3e-5
@@ -66,8 +66,8 @@ def test_stage_graphs(tag, nets, weights):
     rows = lambda x: dev(x.flatten(2).transpose(1, 2))   # noqa: E731
     l4 = torch.empty(k, 16 * h * w, device="cuda")
     agg = torch.empty(k + 1, nh * nw, device="cuda")
-    call("stcn_test_decode", model_handle(nets), stream(), ptr(dev(ro)), ptr(rows(okf2[1])), ptr(rows(okf2[3])),
-         ptr(rows(okf2[4])), k, nh, nw, ptr(l4), ptr(agg))
+    call("stcn_test_decode", model_handle(nets), stream(), dev(ro), rows(okf2[1]), rows(okf2[3]),
+         rows(okf2[4]), k, nh, nw, l4, agg)
     assert (l4.cpu().reshape(ol4.shape) - ol4).abs().max() < 2e-4 * max(1.0, ol4.abs().max().item())
     d = (agg.cpu().reshape(oagg.shape) - oagg).abs().numpy()
     assert np.quantile(d, 0.999) < 1e-3          # saturated multi-object pixels are ill-conditioned
@@ -87,8 +87,8 @@ def test_fusion_net(tag, nets, weights):
     attn = torch.from_numpy(rng.uniform(0, 0.2, (1, 2, nh, nw)).astype(np.float32))
     ref = O.fusion_net(O.fold_bn(weights[1]), imgs[:, 1], prev, curr, attn, 0.25, 0.75)
     out = torch.empty(nh * nw, device="cuda")
-    call("stcn_test_fusion", model_handle(nets), stream(), ptr(dev(imgs[:, 1])), ptr(dev(prev)), ptr(dev(curr)),
-         ptr(dev(attn)), 0.25, 0.75, nh, nw, ptr(out))
+    call("stcn_test_fusion", model_handle(nets), stream(), dev(imgs[:, 1]), dev(prev), dev(curr),
+         dev(attn), 0.25, 0.75, nh, nw, out)
     assert (out.cpu().reshape(ref.shape) - ref).abs().max() < 2e-4
     assert np.abs(sample_of(out, 13) - g[f"{tag}.fusion_logit.sample"]).max() < 2e-4
 
