@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py - frames/sec of STCN mask propagation (480p, 1 object) on N MI355X.
+
+Contract: ``python bench.py --gpus N --steps K --warmup W`` (N>1: launched by torch.distributed.run, one
+rank per GPU).  One STEP = one pass of the hot path over one synthetic video: the first
+``InferenceCore.interact(mask, 0)`` on a fresh engine ("R1"): every one of the T-1
+propagated frames pays key encoder + memory read + decoder + aggregate, every 5th a value encode; mask
+H2D, final argmax and mask D2H are inside the timed region; clip decode/H2D and engine construction are
+not (inputs resident in HBM).  Videos shard across ranks with no data-path collective (weak scaling:
+every rank runs K videos); the only collectives are the timing barrier/max and one gather of per-video
+J&F rows (RCCL over xGMI).
+
+Output: ONE JSON line on rank 0 (see the task contract) with two extra objects:
+  roofline     - dominant kernel (fp32 implicit-GEMM conv): algorithmic FLOP of all conv launches in the
+                 timed region / their summed device time (HIP events on the engine stream) vs the
+                 fp32 MFMA peak 157.3 TFLOP/s (MI355X_MICROARCH.md).
+  cpu_baseline - the CPU oracle (oracle/stcn_oracle.py, a port validated against the reference) timed on
+                 this box's host cores on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=66, help="frames per video (DAVIS-17 val mean length ~66)")
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--width", type=int, default=854)
+    ap.add_argument("--mem-freq", type=int, default=5)
+    ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the bounded CPU-oracle sample (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true", help="skip per-kernel HIP-event timing (roofline = null)")
+    ap.add_argument("--r2", action="store_true", help="also time a second interaction (cached keys + fusion)")
+    return ap.parse_args()
+
+
+def cpu_baseline(psd, fsd, H, W, frames, mem_freq):
+    """Oracle (kind 'port') on the host cores: interact(mask, 0) on a `frames`-long clip of the same shape."""
+    from eva_vos_amd import synth
+    from oracle.stcn_oracle import OracleCore
+    from oracle import stcn_oracle as O
+    img, msk = synth.synthetic_clip(frames, H, W), synth.synthetic_mask(frames, H, W, 1)
+    # pick the intra-op thread count that is fastest on this host (hundreds of threads thrash on the
+    # small GEMMs of the path): one key-encoder pass per candidate
+    fw = O.fold_bn(psd)
+    x0, _ = O.pad16(img[:, 0])
+    best_t, best = 1, float("inf")
+    for nt in sorted({n for n in (8, 16, 32, 64, os.cpu_count() or 1) if n <= (os.cpu_count() or 1)}):
+        torch.set_num_threads(nt)
+        t0 = time.perf_counter()
+        O.encode_key(fw, x0)
+        el = time.perf_counter() - t0
+        if el < best:
+            best_t, best = nt, el
+    torch.set_num_threads(best_t)
+    core = OracleCore(psd, fsd, img, 1, mem_freq=mem_freq)
+    t0 = time.perf_counter()
+    core.interact(msk[:, 0], 0)
+    dt = time.perf_counter() - t0
+    return dict(value=(frames - 1) / dt, unit="frames/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"oracle OracleCore.interact(mask,0) on a {frames}-frame {H}x{W} synthetic clip "
+                       f"({frames - 1} propagated frames, {dt:.1f} s, torch {torch.__version__} CPU)")
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    torch.set_grad_enabled(False)
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (there is no CPU fallback of the product)"
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from eva_vos_amd import metrics, shard, synth
+    from eva_vos_amd.params import FusionNet, PropagationNetwork
+    from mivos.inference_core import InferenceCore
+
+    prop, fuse = PropagationNetwork(), FusionNet()
+    psd, fsd = synth.recipe_state_dict(prop), synth.recipe_state_dict(fuse)
+    prop.load_state_dict(psd)
+    fuse.load_state_dict(fsd)
+
+    T, H, W = a.frames, a.height, a.width
+    img = synth.synthetic_clip(T, H, W).cuda()
+    gt = synth.synthetic_mask(T, H, W, 1)
+    mask0 = gt[:, 0].clone()
+    mask_mid = gt[:, T // 2].clone()
+
+    n_eng = a.warmup + a.steps
+    engines = [InferenceCore(prop, fuse, img, 1, mem_freq=a.mem_freq) for _ in range(n_eng)]
+    for e in engines[: a.warmup]:
+        e.interact(mask0, 0)
+        if a.r2:
+            e.interact(mask_mid, T // 2)
+    timed = engines[a.warmup:]
+    if not a.no_profile:
+        for e in timed:
+            e.set_profiling(True)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    frames = 0
+    last = None
+    for e in timed:
+        last = e.interact(mask0, 0)
+        frames += e.stats()["frames"]
+    torch.cuda.synchronize()
+    dt_r1 = time.perf_counter() - t0
+    barrier()
+    dt = time.perf_counter() - t0
+
+    prof = None
+    if not a.no_profile:
+        prof = {}
+        for e in timed:
+            for cls, v in e.kernel_profile().items():
+                acc = prof.setdefault(cls, dict(ms=0.0, launches=0, flops=0.0))
+                for k_ in acc:
+                    acc[k_] += v[k_]
+
+    r2 = None
+    if a.r2:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        f2 = 0
+        for e in timed:
+            e.interact(mask_mid, T // 2)
+            f2 += e.stats()["frames"]
+        torch.cuda.synchronize()
+        r2 = f2 / (time.perf_counter() - t1)
+
+    # whole-job numbers: max time over ranks, frames summed over ranks
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        ff = torch.tensor([frames], dtype=torch.float64, device="cuda")
+        dist.all_reduce(ff, op=dist.ReduceOp.SUM)
+        dt_all, frames_all = float(tt.item()), float(ff.item())
+    else:
+        dt_all, frames_all = dt, float(frames)
+
+    # per-video J&F rows of the last video of each rank, gathered once (the path's only exchange step)
+    lw, uw, lh, uh = timed[-1].pad
+    sc = metrics.sequence_scores(gt[0, :, 0].numpy() > 0.5, last > 0, every=max(1, T // 6))
+    row = np.array([[rank, sc[1:, 1].mean(), sc[1:, 2].mean(), sc[1:, 3].mean()]], np.float32)
+    rows = shard.gather_rows(row, 4)
+
+    if rank == 0:
+        out = {
+            "metric": "frames/sec STCN mask-propagate 480p 1-obj",
+            "value": frames_all / dt_all, "unit": "frames/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * dt_all / a.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"DAVIS-17-val-shaped {H}x{W} (padded {timed[0].nh}x{timed[0].nw}) single-object "
+                                   f"STCN propagate: fresh engine, interact(mask,0), T={T} frames/video, "
+                                   f"mem_freq={a.mem_freq}, top_k=50; one video per step per GPU",
+                       "frames_per_step": T - 1, "videos_per_gpu": a.steps, "sharding": f"videos x{world}",
+                       "weights": "synthetic recipe seed 0 (no checkpoints offline)"},
+            "ms_per_frame": 1e3 * dt_all / (frames_all / world),
+            "jf_rows_rank_J_F_JF": rows.round(4).tolist(),
+        }
+        if r2 is not None:
+            out["r2_frames_per_s_rank0"] = r2
+        if prof is not None:
+            conv = prof["conv"]
+            ach = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
+            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                               "kernel": "conv_gemm_kernel (fp32 implicit-GEMM conv, v_mfma_f32_32x32x2_f32)",
+                               "launches": conv["launches"], "avg_launch_ms": conv["ms"] / max(conv["launches"], 1),
+                               "flop_per_launch_avg": conv["flops"] / max(conv["launches"], 1)}
+            tot_ms = sum(v["ms"] for v in prof.values())
+            out["kernel_time_share"] = {c: round(v["ms"] / tot_ms, 4) for c, v in prof.items() if v["ms"] > 0}
+            out["device_busy_frac"] = tot_ms * 1e-3 / dt_r1
+            out["algorithmic_gflop_per_frame"] = sum(v["flops"] for v in prof.values()) / frames / 1e9
+        else:
+            out["roofline"] = None
+        if world == 1 and a.cpu_frames > 1:
+            out["cpu_baseline"] = cpu_baseline(psd, fsd, H, W, a.cpu_frames, a.mem_freq)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

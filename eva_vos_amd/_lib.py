@@ -8,6 +8,9 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+import torch  # noqa: F401  (first: PyTorch-ROCm bundles its own libamdhip64/libhsa-runtime64; loading them
+#               before libstcn_hip.so makes the process use ONE HIP runtime, whatever the import order)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libstcn_hip.so")
 

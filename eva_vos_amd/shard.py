@@ -1,0 +1,50 @@
+"""Per-video sharding across the GPUs of one node and the single collective of the path.
+
+Every dataset sample is one (video, object) with its own InferenceCore and no shared state
+(reference interactions/eval.py:92-99, generate_fq_dataset.py:60-69); the reference shards evaluation
+by ``--min-idx/--max-idx`` (eval_annotation_method.py:34-35).  Here: one process per GPU, a static
+longest-processing-time assignment of samples to ranks (work ~ frame count), NO collective inside
+propagation, and one end-of-run gather of fixed-width per-sample rows (RCCL over xGMI when the
+backend is "nccl"; "gloo" in the CPU tests)."""
+from __future__ import annotations
+
+from typing import List, Sequence
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def lpt_assign(costs: Sequence[float], world: int) -> List[List[int]]:
+    """Deterministic LPT: heaviest sample first onto the least-loaded rank (ties -> lowest rank)."""
+    order = sorted(range(len(costs)), key=lambda i: (-costs[i], i))
+    load = [0.0] * world
+    out: List[List[int]] = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda j: (load[j], j))
+        out[r].append(i)
+        load[r] += costs[i]
+    return out
+
+
+def gather_rows(rows: np.ndarray, width: int, device=None) -> np.ndarray:
+    """All ranks contribute a [n_r, width] float32 array (n_r may differ); every rank gets the
+    concatenation ordered by the rows' first column (sample id), so the result does not depend on which
+    rank processed which sample."""
+    rows = np.asarray(rows, np.float32).reshape(-1, width)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return rows[np.argsort(rows[:, 0], kind="stable")]
+    world = dist.get_world_size()
+    dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device())
+                                             if dist.get_backend() == "nccl" else torch.device("cpu"))
+    n = torch.tensor([rows.shape[0]], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)
+    nmax = int(max(int(c.item()) for c in counts))
+    buf = torch.full((max(nmax, 1), width), float("nan"), dtype=torch.float32, device=dev)
+    if rows.shape[0]:
+        buf[: rows.shape[0]] = torch.from_numpy(rows).to(dev)
+    parts = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(parts, buf)
+    out = np.concatenate([p[: int(c.item())].cpu().numpy() for p, c in zip(parts, counts)], 0)
+    return out[np.argsort(out[:, 0], kind="stable")]

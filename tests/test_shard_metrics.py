@@ -1,0 +1,74 @@
+"""CPU: per-video sharding (world_size 2 over gloo) and the J / F metrics."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from eva_vos_amd import metrics, shard
+
+
+def test_lpt_is_balanced_and_deterministic():
+    costs = [104, 34, 50, 82, 66, 40, 90, 71, 36, 59]
+    a = shard.lpt_assign(costs, 4)
+    assert a == shard.lpt_assign(costs, 4)
+    assert sorted(i for r in a for i in r) == list(range(len(costs)))
+    loads = [sum(costs[i] for i in r) for r in a]
+    assert max(loads) - min(loads) <= max(costs) // 2
+    assert shard.lpt_assign(costs, 1) == [sorted(range(len(costs)), key=lambda i: (-costs[i], i))]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    costs = [10, 3, 7, 5, 9]
+    mine = shard.lpt_assign(costs, world)[rank]
+    rows = np.array([[i, costs[i] * 0.5, rank] for i in mine], np.float32)
+    out = shard.gather_rows(rows, 3)
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_rows_world2_gloo():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    got = dict(q.get(timeout=120) for _ in range(2))
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    for r in range(2):
+        assert got[r][:, 0].tolist() == [0, 1, 2, 3, 4]          # ordered by sample id on every rank
+        assert np.allclose(got[r][:, 1], [5, 1.5, 3.5, 2.5, 4.5])
+    assert np.array_equal(got[0], got[1])
+    assert set(got[0][:, 2].tolist()) == {0.0, 1.0}              # both ranks contributed
+
+
+def test_gather_rows_single_process_sorts():
+    out = shard.gather_rows(np.array([[3, 1], [1, 2], [2, 3]], np.float32), 2)
+    assert out[:, 0].tolist() == [1, 2, 3]
+
+
+def test_j_and_f_known_answers():
+    gt = np.zeros((40, 60), bool)
+    gt[10:30, 20:40] = True
+    assert metrics.jaccard(gt, gt) == 1.0 and metrics.f_measure(gt, gt) == 1.0
+    assert metrics.j_and_f(gt, gt) == 1.0
+    empty = np.zeros_like(gt)
+    assert metrics.jaccard(gt, empty) == 0.0 and metrics.f_measure(gt, empty) == 0.0     # n_fg == 0, n_gt > 0
+    assert metrics.f_measure(empty, empty) == 1.0 and metrics.jaccard(empty, empty) == 0.0
+    shifted = np.roll(gt, 1, axis=1)                                                     # within the 1-px tolerance
+    assert metrics.f_measure(gt, shifted) == 1.0
+    assert abs(metrics.jaccard(gt, shifted) - (19 * 20) / (21 * 20)) < 1e-12
+    far = np.roll(gt, 12, axis=1)
+    assert metrics.f_measure(gt, far) < 0.7
+    b = metrics.boundary_map(gt)
+    assert b.sum() == 2 * 20 + 2 * 20 and b[9, 19] and not b[10, 20]                     # half-pixel offset to origin
+    rows = metrics.sequence_scores(np.stack([gt, gt]), np.stack([gt, empty]))
+    assert rows.shape == (2, 4) and rows[0, 3] == 1.0 and rows[1, 3] == 0.0

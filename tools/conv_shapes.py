@@ -1,0 +1,67 @@
+"""Per-shape throughput of the implicit-GEMM conv kernel on the layer shapes of the STCN path
+(SURVEY.md Table K).  Usage (GPU box): python tools/conv_shapes.py [--splitk S]"""
+import ctypes as C
+import sys
+
+import torch
+
+sys.path.insert(0, ".")
+from eva_vos_amd import _lib  # noqa: E402
+
+#        name                      B  H    W    Cin   Cout K s  count/frame
+SHAPES = [
+    ("key.stem 7x7s2",            1, 480, 864, 4,    64,  7, 2, 1),
+    ("key.res2 1x1 64->64",       1, 120, 216, 64,   64,  1, 1, 1),
+    ("key.res2 3x3 64",           1, 120, 216, 64,   64,  3, 1, 3),
+    ("key.res2 1x1 64->256",      1, 120, 216, 64,   256, 1, 1, 4),
+    ("key.res2 1x1 256->64",      1, 120, 216, 256,  64,  1, 1, 2),
+    ("key.l2 1x1 256->128",       1, 120, 216, 256,  128, 1, 1, 1),
+    ("key.l2 3x3s2 128",          1, 120, 216, 128,  128, 3, 2, 1),
+    ("key.l2 1x1 128->512",       1, 60,  108, 128,  512, 1, 1, 4),
+    ("key.l2 ds 1x1s2 256->512",  1, 120, 216, 256,  512, 1, 2, 1),
+    ("key.l2 1x1 512->128",       1, 60,  108, 512,  128, 1, 1, 3),
+    ("key.l2 3x3 128",            1, 60,  108, 128,  128, 3, 1, 3),
+    ("key.l3 1x1 512->256",       1, 60,  108, 512,  256, 1, 1, 1),
+    ("key.l3 3x3s2 256",          1, 60,  108, 256,  256, 3, 2, 1),
+    ("key.l3 1x1 256->1024",      1, 30,  54,  256,  1024, 1, 1, 6),
+    ("key.l3 ds 1x1s2 512->1024", 1, 60,  108, 512,  1024, 1, 2, 1),
+    ("key.l3 1x1 1024->256",      1, 30,  54,  1024, 256, 1, 1, 5),
+    ("key.l3 3x3 256",            1, 30,  54,  256,  256, 3, 1, 5),
+    ("key_proj 3x3 1024->64",     1, 30,  54,  1024, 64,  3, 1, 1),
+    ("key_comp 3x3 1024->512",    1, 30,  54,  1024, 512, 3, 1, 1),
+    ("dec.skip8 3x3 512",         1, 60,  108, 512,  512, 3, 1, 1),
+    ("dec.skip4 3x3 256",         1, 120, 216, 256,  256, 3, 1, 1),
+    ("dec.compress 3x3 1024->512", 1, 30, 54,  1024, 512, 3, 1, 2),
+    ("dec 3x3 512->512 @16",      1, 30,  54,  512,  512, 3, 1, 1),
+    ("dec 3x3 512->256 @8",       1, 60,  108, 512,  256, 3, 1, 2),
+    ("dec 3x3 256->256 @8",       1, 60,  108, 256,  256, 3, 1, 1),
+    ("dec 3x3 256->256 @4",       1, 120, 216, 256,  256, 3, 1, 2),
+    ("val.stem 7x7s2 8->64",      1, 480, 864, 8,    64,  7, 2, 0.2),
+    ("val.l1 3x3 64",             1, 120, 216, 64,   64,  3, 1, 0.8),
+    ("val.fuser 3x3 1280->512",   1, 30,  54,  1280, 512, 3, 1, 0.4),
+    ("val.fuser 3x3 512->512",    1, 30,  54,  512,  512, 3, 1, 0.6),
+    ("fuse 3x3 12->32",           1, 480, 864, 12,   32,  3, 1, 0),
+    ("fuse 3x3 32->32",           1, 480, 864, 32,   32,  3, 1, 0),
+]
+
+
+def main():
+    splitk = int(sys.argv[sys.argv.index("--splitk") + 1]) if "--splitk" in sys.argv else 0
+    lib = _lib.lib()
+    torch.cuda.init()
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    tot_ms = tot_fl = 0.0
+    print(f"{'layer':30s} {'M':>7s} {'N':>5s} {'K':>6s} {'ms':>8s} {'TFLOP/s':>8s} {'ms/frame':>9s}")
+    for name, B, H, W, Cin, Cout, K, st, cnt in SHAPES:
+        ms, fl = C.c_float(), C.c_double()
+        _lib.check(lib.stcn_bench_conv(s, B, H, W, Cin, Cout, K, K, st, K // 2, splitk, 20, C.byref(ms), C.byref(fl)))
+        OH, OW = (H + 2 * (K // 2) - K) // st + 1, (W + 2 * (K // 2) - K) // st + 1
+        tf = fl.value / (ms.value * 1e-3) / 1e12
+        tot_ms += ms.value * cnt
+        tot_fl += fl.value * cnt
+        print(f"{name:30s} {B*OH*OW:7d} {Cout:5d} {K*K*Cin:6d} {ms.value:8.4f} {tf:8.1f} {ms.value*cnt:9.3f}")
+    print(f"weighted per R1 frame: {tot_ms:.3f} ms, {tot_fl/1e9:.1f} GFLOP, {tot_fl/tot_ms/1e9:.1f} TFLOP/s")
+
+
+if __name__ == "__main__":
+    main()
