@@ -21,6 +21,8 @@
 //   * split-K over K tiles with an fp32 slab workspace + a vectorised reduce/epilogue kernel; the
 //     host picks the split so that tiles*split fills the 256 CUs in whole rounds.
 //   * XCD-aware block remap: each XCD (own L2) gets a contiguous range of (m-tile, n-tile) pairs.
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace stcn {
@@ -31,7 +33,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 static constexpr int BK = 32;
 static constexpr int LDT = 36;
 
-template <int WM, int WN, bool SMALLC>
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+static constexpr unsigned OOB = 0x80000000u;    // byte offset beyond any tensor: buffer loads return 0
+
+template <int WM, int WN, bool SMALLC, bool RELU>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvP p, const int tiles_n,
                                                         const int ntile, const int kt_per_split) {
     constexpr int BM = 32 * WM, BN = 32 * WN;
@@ -51,8 +56,16 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvP p, const int
     const int wm = wave / WN, wn = wave - wm * WN;
     const int kc = t & 7, r0 = t >> 3;
 
-    // ---- per-thread im2col row state (rows r0 + 32*i of the A tile); 32-bit element offsets
-    int ih0[WM], iw0[WM], base0[WM], base1[WM];
+    // Buffer resources: out-of-range byte offsets read as zero in hardware, so padding taps, ragged
+    // rows/columns and the K tail need no data fix-up (the fp32 MFMA shares the SIMD's FMA lanes with
+    // VALU work - measured: MFMA-busy + VALU + LDS cycles add up - so every VALU op here costs MFMA time).
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x0), 0, p.x0_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x1 ? p.x1 : p.x0), 0, p.x1 ? p.x1_bytes : p.x0_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w), 0, p.w_bytes, 0x00020000);
+
+    // ---- per-thread im2col row state (rows r0 + 32*i of the A tile)
+    int ih0[WM], iw0[WM], roff0[WM], roff1[WM];      // roffX: byte offset of (b, ih0, iw0, channel kc*4) in source X
+    unsigned vmask[WM];                               // fast path: bit (kh*KW+kw) = tap inside the image
     bool rvalid[WM];
     const int ohw = p.OH * p.OW;
 #pragma unroll
@@ -64,25 +77,32 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvP p, const int
         const int oh = pix / p.OW, ow = pix - oh * p.OW;
         ih0[i] = oh * p.stride - p.pad;
         iw0[i] = ow * p.stride - p.pad;
-        base0[i] = b * (int)p.bs0 + (ih0[i] * p.W + iw0[i]) * p.c0;
-        base1[i] = b * (int)p.bs1 + (ih0[i] * p.W + iw0[i]) * p.c1;
+        roff0[i] = (b * (int)p.bs0 + (ih0[i] * p.W + iw0[i]) * p.c0 + (SMALLC ? 0 : kc * 4)) * 4;
+        roff1[i] = (b * (int)p.bs1 + (ih0[i] * p.W + iw0[i]) * p.c1 + (SMALLC ? 0 : kc * 4)) * 4;
+        unsigned vm = 0;
+        if (!SMALLC) {
+            int bit = 0;
+            for (int kh = 0; kh < p.KH; ++kh)
+                for (int kw = 0; kw < p.KW; ++kw, ++bit)
+                    if (rvalid[i] && (unsigned)(ih0[i] + kh) < (unsigned)p.H && (unsigned)(iw0[i] + kw) < (unsigned)p.W)
+                        vm |= 1u << bit;
+        }
+        vmask[i] = vm;
     }
-    const float *wrow[WN];
-    bool nvalid[WN];
+    unsigned woff[WN];                                // byte offset of weight row n, chunk kc (OOB when n >= N)
 #pragma unroll
     for (int i = 0; i < WN; ++i) {
         const int n = tn * BN + r0 + 32 * i;
-        nvalid[i] = n < p.N;
-        wrow[i] = p.w + (long)(nvalid[i] ? n : 0) * p.Kp + kc * 4;
+        woff[i] = n < p.N ? (unsigned)((n * p.Kp + kc * 4) * 4) : OOB;
     }
 
     const int nkt = p.Kp / BK;
     const int kt0 = split * kt_per_split;
     const int kt1 = min(nkt, kt0 + kt_per_split);
 
-    // Filter-tap walk.  Fast path (Cin and c0 multiples of 32): a K tile lies inside one tap and one
-    // source, so (kh, kw, channel base) are workgroup-uniform and advance incrementally (scalar unit).
-    // Small-Cin path (stems, Cin = 4/8/12): per-thread decode of its 4-channel chunk.
+    // Filter-tap walk.  Fast path (Cin and c0 multiples of 32, <= 32 taps): a K tile lies inside one tap
+    // and one source, so tap / source / channel base are workgroup-uniform and live in scalar registers.
+    // Generic path (stems, Cin = 4/8/12): per-thread decode of its 4-channel chunk.
     int u_kh, u_kw, u_cb;
     {
         const int k0 = kt0 * BK;
@@ -92,91 +112,136 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvP p, const int
         u_kw = tap - u_kh * p.KW;
     }
 
-    // gload() only ISSUES the loads (raw data + validity bits); the zero/ReLU fix-up happens in
-    // lstore(), after the MFMAs of the current tile, so the loads stay in flight under the MFMAs.
-    f32x4 ra[WM], rb[WN];
-    unsigned okmask = 0;
-    auto gload = [&](int kt) {
-        int kh, kw, c;
-        bool kvalid = true;
+    // Software pipeline (one K tile = 16 MFMAs = 1024 matrix-pipe cycles per wave):
+    //   iteration t runs C(t) = LDS->MFMA and, between those MFMAs,
+    //     G(t+2): global -> staging registers (buffer loads, issued right after the first MFMAs),
+    //     S(t+1): staging registers -> the other LDS buffer (after the later MFMAs).
+    //   Two staging register sets (tile parity) give every load ~1.5 iterations to land before its
+    //   write-back; sched_barrier pins the placement (hipcc otherwise sinks the loads to the loop end).
+    f32x4 ra[2][WM], rb[2][WN];
+    // per-tile uniform (fast path) / per-thread (generic) tap state produced by g_tap
+    int g_kh = 0, g_kw = 0, g_coff = 0;
+    unsigned g_bit = 0;
+    bool g_src1 = false, g_kvalid = true;
+    auto g_tap = [&](int kt) {
         if (SMALLC) {
             const int k = kt * BK + kc * 4;
-            kvalid = k < p.K;
+            g_kvalid = k < p.K;
             const int tap = k / p.Cin;
-            c = k - tap * p.Cin;
-            kh = tap / p.KW;
-            kw = tap - kh * p.KW;
+            const int c = k - tap * p.Cin;
+            g_kh = tap / p.KW;
+            g_kw = tap - g_kh * p.KW;
+            g_coff = ((g_kh * p.W + g_kw) * p.c0 + c) * 4;
         } else {
-            kh = u_kh; kw = u_kw; c = u_cb + kc * 4;
+            g_src1 = u_cb >= p.c0;
+            g_bit = (unsigned)(u_kh * p.KW + u_kw);
+            const int cs = g_src1 ? p.c1 : p.c0;
+            g_coff = ((u_kh * p.W + u_kw) * cs + (g_src1 ? u_cb - p.c0 : u_cb)) * 4;
             u_cb += BK;
             if (u_cb >= p.Cin) { u_cb = 0; if (++u_kw == p.KW) { u_kw = 0; ++u_kh; } }
         }
-        const bool src1 = c >= p.c0;
-        const float *sbase = src1 ? p.x1 : p.x0;
-        const int cs = src1 ? p.c1 : p.c0;
-        const int coff = (kh * p.W + kw) * cs + (src1 ? c - p.c0 : c);
-        okmask = 0;
-#pragma unroll
-        for (int i = 0; i < WM; ++i) {
-            // branch-free gather: out-of-image / out-of-range chunks read a safe address
-            const bool ok = kvalid && rvalid[i] && (unsigned)(ih0[i] + kh) < (unsigned)p.H &&
-                            (unsigned)(iw0[i] + kw) < (unsigned)p.W;
-            const int off = ok ? (src1 ? base1[i] : base0[i]) + coff : 0;
-            okmask |= (ok ? 1u : 0u) << i;
-            ra[i] = *reinterpret_cast<const f32x4 *>(sbase + off);
-        }
-#pragma unroll
-        for (int i = 0; i < WN; ++i) rb[i] = *reinterpret_cast<const f32x4 *>(wrow[i] + (long)kt * BK);
     };
-    const float relu_lo = p.relu_in ? 0.f : -__builtin_inff();
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < WM; ++i) {
-            const bool ok = (okmask >> i) & 1u;
-            f32x4 v = ra[i];
-            v.x = ok ? fmaxf(v.x, relu_lo) : 0.f; v.y = ok ? fmaxf(v.y, relu_lo) : 0.f;
-            v.z = ok ? fmaxf(v.z, relu_lo) : 0.f; v.w = ok ? fmaxf(v.w, relu_lo) : 0.f;
-            *reinterpret_cast<f32x4 *>(&As[(buf * BM + r0 + 32 * i) * LDT + kc * 4]) = v;
-        }
-#pragma unroll
-        for (int i = 0; i < WN; ++i) {
-            f32x4 v = rb[i];
-            if (!nvalid[i]) v = f32x4{0.f, 0.f, 0.f, 0.f};
-            *reinterpret_cast<f32x4 *>(&Bs[(buf * BN + r0 + 32 * i) * LDT + kc * 4]) = v;
+    auto g_a = [&](int i, auto setc) {
+        constexpr int ST = decltype(setc)::value;
+        unsigned voff;
+        if (SMALLC) {
+            const bool ok = g_kvalid && rvalid[i] && (unsigned)(ih0[i] + g_kh) < (unsigned)p.H &&
+                            (unsigned)(iw0[i] + g_kw) < (unsigned)p.W;
+            voff = ok ? (unsigned)(roff0[i] + g_coff) : OOB;
+            ra[ST][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, voff, 0, 0));
+        } else {
+            const bool ok = (vmask[i] >> g_bit) & 1u;
+            voff = ok ? (unsigned)((g_src1 ? roff1[i] : roff0[i]) + g_coff) : OOB;
+            ra[ST][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_src1 ? rs1 : rs0, voff, 0, 0));
         }
     };
+    auto g_b = [&](int i, int kt, auto setc) {
+        constexpr int ST = decltype(setc)::value;
+        rb[ST][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, woff[i], kt * (BK * 4), 0));
+    };
+    float *const a_st = As + r0 * LDT + kc * 4;
+    float *const b_st = Bs + r0 * LDT + kc * 4;
+    auto s_a = [&](int i, int buf, auto setc) {
+        constexpr int ST = decltype(setc)::value;
+        f32x4 v = ra[ST][i];
+        if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *reinterpret_cast<f32x4 *>(a_st + (buf * BM + 32 * i) * LDT) = v;
+    };
+    auto s_b = [&](int i, int buf, auto setc) {
+        constexpr int ST = decltype(setc)::value;
+        *reinterpret_cast<f32x4 *>(b_st + (buf * BN + 32 * i) * LDT) = rb[ST][i];
+    };
+    auto gload_all = [&](int kt, auto setc) {
+        g_tap(kt);
+#pragma unroll
+        for (int i = 0; i < WM; ++i) g_a(i, setc);
+#pragma unroll
+        for (int i = 0; i < WN; ++i) g_b(i, kt < nkt ? kt : nkt - 1, setc);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
 
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
-    if (kt0 < kt1) {
-        gload(kt0);
-        lstore(0);
+    const int nk = kt1 - kt0;
+    if (nk > 0) {
+        gload_all(kt0, I0{});
+#pragma unroll
+        for (int i = 0; i < WM; ++i) s_a(i, 0, I0{});
+#pragma unroll
+        for (int i = 0; i < WN; ++i) s_b(i, 0, I0{});
+        gload_all(kt0 + 1, I1{});                  // tile 1 -> set 1 (past the K range: zeros / last tile)
     }
     __syncthreads();
 
     const int arow = (wm * 32 + (lane & 31)) * LDT + (lane >> 5) * 4;
     const int brow = (wn * 32 + (lane & 31)) * LDT + (lane >> 5) * 4;
-    for (int kt = kt0; kt < kt1; ++kt) {
-        const int buf = (kt - kt0) & 1;
-        const bool more = kt + 1 < kt1;
-        if (more) gload(kt + 1);
+    constexpr int NPIECE = WM + WN;
+    // iteration `it`: C(it) from LDS buffer it&1; G(it+2) -> register set it&1;
+    //                 S(it+1) from the other set -> LDS buffer (it+1)&1
+    auto iteration = [&](int it, auto gsc) {
+        constexpr int GS = decltype(gsc)::value;
+        using SS = std::integral_constant<int, GS ^ 1>;
+        constexpr int buf = GS;
+        const int kt2 = kt0 + it + 2;
+        const int kt2c = kt2 < nkt ? kt2 : nkt - 1;    // weights: stay inside the [N][Kp] array
         const float *a_s = As + buf * BM * LDT + arow;
         const float *b_s = Bs + buf * BN * LDT + brow;
+        f32x4 fa[2], fb[2];
+        fa[0] = *reinterpret_cast<const f32x4 *>(a_s);
+        fb[0] = *reinterpret_cast<const f32x4 *>(b_s);
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-            const f32x4 a = *reinterpret_cast<const f32x4 *>(a_s + kb * 8);
-            const f32x4 b = *reinterpret_cast<const f32x4 *>(b_s + kb * 8);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+            const int cur = kb & 1;
+            if (kb < 3) {                              // prefetch the next fragment pair
+                fa[cur ^ 1] = *reinterpret_cast<const f32x4 *>(a_s + (kb + 1) * 8);
+                fb[cur ^ 1] = *reinterpret_cast<const f32x4 *>(b_s + (kb + 1) * 8);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][j], fb[cur][j], acc, 0, 0, 0);
+                // staging pieces between the MFMAs (unconditional: a branch per piece makes hipcc drain
+                // vmcnt(0) at every block boundary; on the tail iterations they fetch zeros / the last
+                // weight tile and write the unused LDS buffer, which is harmless)
+                const int slot = 4 * kb + j;
+                if (slot == 0) g_tap(kt2);
+                else if (slot <= WM) g_a(slot - 1, gsc);
+                else if (slot <= NPIECE) g_b(slot - 1 - WM, kt2c, gsc);
+                else if (slot >= 15 - NPIECE && slot < 15 - WN) s_a(slot - (15 - NPIECE), buf ^ 1, SS{});
+                else if (slot >= 15 - WN && slot < 15) s_b(slot - (15 - WN), buf ^ 1, SS{});
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        __builtin_amdgcn_sched_barrier(0);   // keep the staging write-back behind the MFMAs
-        if (more) lstore(buf ^ 1);
         __syncthreads();
+    };
+    int it = 0;
+    for (; it + 1 < nk; it += 2) {
+        iteration(it, I0{});
+        iteration(it + 1, I1{});
     }
+    if (it < nk) iteration(it, I0{});
 
     // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int n = tn * BN + wn * 32 + (lane & 31);
@@ -273,15 +338,21 @@ void conv_launch(const ConvP &p, hipStream_t s) {
     const int per = (nkt + p.splitk - 1) / p.splitk;
     const size_t lds = (size_t)2 * (BM + BN) * LDT * sizeof(float);
     const dim3 grid(ntile * p.splitk);
-    const bool smallc = (p.Cin % 32) != 0 || (p.x1 && (p.c0 % 32) != 0);
-    if (narrow && smallc)
-        hipLaunchKernelGGL((conv_gemm_kernel<4, 1, true>), grid, dim3(256), lds, s, p, tiles_n, ntile, per);
-    else if (narrow)
-        hipLaunchKernelGGL((conv_gemm_kernel<4, 1, false>), grid, dim3(256), lds, s, p, tiles_n, ntile, per);
-    else if (smallc)
-        hipLaunchKernelGGL((conv_gemm_kernel<2, 2, true>), grid, dim3(256), lds, s, p, tiles_n, ntile, per);
-    else
-        hipLaunchKernelGGL((conv_gemm_kernel<2, 2, false>), grid, dim3(256), lds, s, p, tiles_n, ntile, per);
+    const bool smallc = (p.Cin % 32) != 0 || (p.x1 && (p.c0 % 32) != 0) || p.KH * p.KW > 32;
+#define STCN_LAUNCH(WM_, WN_, SC_, RL_) \
+    hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, SC_, RL_>), grid, dim3(256), lds, s, p, tiles_n, ntile, per)
+    const int key = (narrow ? 4 : 0) | (smallc ? 2 : 0) | (p.relu_in ? 1 : 0);
+    switch (key) {
+        case 0: STCN_LAUNCH(2, 2, false, false); break;
+        case 1: STCN_LAUNCH(2, 2, false, true); break;
+        case 2: STCN_LAUNCH(2, 2, true, false); break;
+        case 3: STCN_LAUNCH(2, 2, true, true); break;
+        case 4: STCN_LAUNCH(4, 1, false, false); break;
+        case 5: STCN_LAUNCH(4, 1, false, true); break;
+        case 6: STCN_LAUNCH(4, 1, true, false); break;
+        default: STCN_LAUNCH(4, 1, true, true); break;
+    }
+#undef STCN_LAUNCH
     if (p.splitk > 1) {
         const long total4 = (long)p.M * p.N / 4;
         long blocks = (total4 + 255) / 256;

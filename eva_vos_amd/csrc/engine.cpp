@@ -235,6 +235,10 @@ int run_conv(const Model &m, Work &w, hipStream_t s, const char *name, const flo
     p.OW = (W + 2 * p.pad - cw.kw) / stride + 1;
     p.Cin = cw.cin_p;
     p.M = B * p.OH * p.OW; p.N = cw.cout; p.K = cw.K; p.Kp = cw.Kp;
+    p.x0_bytes = (unsigned)(((bs0 ? (long)B * bs0 : (long)H * W * c0)) * 4);
+    p.x1_bytes = x1 ? (unsigned)(((bs1 ? (long)B * bs1 : (long)H * W * c1)) * 4) : 0u;
+    p.w_bytes = (unsigned)((long)cw.cout * cw.Kp * 4);
+    if (x1 && ((cw.cin_p % 32) || (c0 % 32) || cw.kh * cw.kw > 32)) { set_error("conv '%s': two-source input needs 32-aligned channel splits", name); return STCN_E_INVALID; }
     p.w = cw.w; p.bias = cw.bias; p.res = res; p.res_bs = res_bs; p.y = y; p.y_bs = y_bs;
     p.relu_in = relu_in; p.relu_out = relu_out;
     p.splitk = force_splitk > 0 ? force_splitk : conv_choose_splitk(p);
@@ -306,8 +310,10 @@ static int resblock(const Model &m, Work &w, hipStream_t s, const std::string &p
         RC(run_conv(m, w, s, (p + ".downsample").c_str(), x0, c0, bs0, x1, c1, bs1, B, H, W, 1, t2, 0, nullptr, 0, 0, 0));
         skip = t2; skip_bs = obs;
     } else { skip = x0; skip_bs = bs0; }
-    RC(run_conv(m, w, s, (p + ".conv1").c_str(), x0, c0, bs0, x1, c1, bs1, B, H, W, 1, t1, 0, nullptr, 0, 1, 0));
-    RC(run_conv(m, w, s, (p + ".conv2").c_str(), t1, cw.cout, obs, nullptr, 0, 0, B, H, W, 1, out, out_bs, skip, skip_bs, 1, 0));
+    // r = conv2(relu(conv1(relu(x)))): the inner ReLU is applied once in conv1's epilogue instead of on every
+    // (9x re-read) operand load of conv2
+    RC(run_conv(m, w, s, (p + ".conv1").c_str(), x0, c0, bs0, x1, c1, bs1, B, H, W, 1, t1, 0, nullptr, 0, 1, 1));
+    RC(run_conv(m, w, s, (p + ".conv2").c_str(), t1, cw.cout, obs, nullptr, 0, 0, B, H, W, 1, out, out_bs, skip, skip_bs, 0, 0));
     return STCN_OK;
 }
 

@@ -11,6 +11,7 @@ struct ConvP {
     const float *x0, *x1;   // sources; x1 == nullptr when unused
     int c0, c1;             // channels of each source (multiples of 4)
     long bs0, bs1;          // batch strides in elements (0 = broadcast over the batch)
+    unsigned x0_bytes, x1_bytes, w_bytes;   // extents for the buffer descriptors (hardware bounds check)
     int B, H, W;            // input batch / spatial
     int OH, OW;
     int KH, KW, stride, pad;

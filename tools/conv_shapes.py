@@ -5,7 +5,8 @@ import sys
 
 import torch
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from eva_vos_amd import _lib  # noqa: E402
 
 #        name                      B  H    W    Cin   Cout K s  count/frame
@@ -47,14 +48,18 @@ SHAPES = [
 
 def main():
     splitk = int(sys.argv[sys.argv.index("--splitk") + 1]) if "--splitk" in sys.argv else 0
+    only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
+    iters = int(sys.argv[sys.argv.index("--iters") + 1]) if "--iters" in sys.argv else 20
     lib = _lib.lib()
     torch.cuda.init()
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     tot_ms = tot_fl = 0.0
     print(f"{'layer':30s} {'M':>7s} {'N':>5s} {'K':>6s} {'ms':>8s} {'TFLOP/s':>8s} {'ms/frame':>9s}")
     for name, B, H, W, Cin, Cout, K, st, cnt in SHAPES:
+        if only and only not in name:
+            continue
         ms, fl = C.c_float(), C.c_double()
-        _lib.check(lib.stcn_bench_conv(s, B, H, W, Cin, Cout, K, K, st, K // 2, splitk, 20, C.byref(ms), C.byref(fl)))
+        _lib.check(lib.stcn_bench_conv(s, B, H, W, Cin, Cout, K, K, st, K // 2, splitk, iters, C.byref(ms), C.byref(fl)))
         OH, OW = (H + 2 * (K // 2) - K) // st + 1, (W + 2 * (K // 2) - K) // st + 1
         tf = fl.value / (ms.value * 1e-3) / 1e12
         tot_ms += ms.value * cnt
