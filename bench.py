@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--mem-freq", type=int, default=5)
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the bounded CPU-oracle sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel HIP-event timing (roofline = null)")
+    ap.add_argument("--streams", type=int, default=1, help="videos in flight per GPU (one host thread + HIP stream each)")
     ap.add_argument("--r2", action="store_true", help="also time a second interaction (cached keys + fusion)")
     return ap.parse_args()
 
@@ -107,11 +108,19 @@ def main():
     mask_mid = gt[:, T // 2].clone()
 
     n_eng = a.warmup + a.steps
-    engines = [InferenceCore(prop, fuse, img, 1, mem_freq=a.mem_freq) for _ in range(n_eng)]
-    for e in engines[: a.warmup]:
-        e.interact(mask0, 0)
-        if a.r2:
-            e.interact(mask_mid, T // 2)
+    # one HIP stream per in-flight video; engines are bound to the stream they are created under
+    S = max(1, min(a.streams, a.steps))
+    streams = [torch.cuda.Stream() for _ in range(S)] if S > 1 else [torch.cuda.current_stream()]
+    engines = []
+    for i in range(n_eng):
+        with torch.cuda.stream(streams[i % S]):
+            engines.append(InferenceCore(prop, fuse, img, 1, mem_freq=a.mem_freq))
+    torch.cuda.synchronize()
+    for i, e in enumerate(engines[: a.warmup]):
+        with torch.cuda.stream(streams[i % S]):
+            e.interact(mask0, 0)
+            if a.r2:
+                e.interact(mask_mid, T // 2)
     timed = engines[a.warmup:]
     if not a.no_profile:
         for e in timed:
@@ -122,17 +131,36 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def run_lane(lane, mask, idx):
+        """Host thread `lane`: its videos one after another on its own stream (ctypes releases the GIL)."""
+        torch.cuda.set_device(local)
+        fr, out = 0, None
+        with torch.cuda.stream(streams[lane]):
+            for j in range(lane, len(timed), S):
+                e = timed[j]
+                assert engines.index(e) % S == lane
+                out = e.interact(mask, idx)
+                fr += e.stats()["frames"]
+        return fr, out
+
+    def run_all(mask, idx):
+        if S == 1:
+            return [run_lane(0, mask, idx)]
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(S) as ex:
+            return list(ex.map(lambda l: run_lane(l, mask, idx), range(S)))
+
+    # lanes must line up with the stream an engine was created on
+    assert a.warmup % S == 0 or S == 1, "--warmup must be a multiple of --streams"
     barrier()
     t0 = time.perf_counter()
-    frames = 0
-    last = None
-    for e in timed:
-        last = e.interact(mask0, 0)
-        frames += e.stats()["frames"]
+    res = run_all(mask0, 0)
     torch.cuda.synchronize()
     dt_r1 = time.perf_counter() - t0
     barrier()
     dt = time.perf_counter() - t0
+    frames = sum(r[0] for r in res)
+    last = res[0][1]
 
     prof = None
     if not a.no_profile:
@@ -147,12 +175,9 @@ def main():
     if a.r2:
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        f2 = 0
-        for e in timed:
-            e.interact(mask_mid, T // 2)
-            f2 += e.stats()["frames"]
+        res2 = run_all(mask_mid, T // 2)
         torch.cuda.synchronize()
-        r2 = f2 / (time.perf_counter() - t1)
+        r2 = sum(r[0] for r in res2) / (time.perf_counter() - t1)
 
     # whole-job numbers: max time over ranks, frames summed over ranks
     if dist is not None:
@@ -181,7 +206,7 @@ def main():
             "config": {"workload": f"DAVIS-17-val-shaped {H}x{W} (padded {timed[0].nh}x{timed[0].nw}) single-object "
                                    f"STCN propagate: fresh engine, interact(mask,0), T={T} frames/video, "
                                    f"mem_freq={a.mem_freq}, top_k=50; one video per step per GPU",
-                       "frames_per_step": T - 1, "videos_per_gpu": a.steps, "sharding": f"videos x{world}",
+                       "frames_per_step": T - 1, "videos_per_gpu": a.steps, "sharding": f"videos x{world}", "streams_per_gpu": S,
                        "weights": "synthetic recipe seed 0 (no checkpoints offline)"},
             "ms_per_frame": 1e3 * dt_all / (frames_all / world),
             "jf_rows_rank_J_F_JF": rows.round(4).tolist(),

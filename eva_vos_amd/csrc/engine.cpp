@@ -212,6 +212,8 @@ int Work::init(int nh, int nw, int k_) {
     if ((rc = alloc((void **)&cand_v, (size_t)16 * d.hw16 * 50 * sizeof(float)))) return rc;
     if ((rc = alloc((void **)&cand_i, (size_t)16 * d.hw16 * 50 * sizeof(int32_t)))) return rc;
     if ((rc = alloc((void **)&vin, (size_t)k * d.npix * 8 * sizeof(float)))) return rc;
+    if ((rc = alloc((void **)&gmax, (size_t)256 * d.hw16 * sizeof(float)))) return rc;
+    if ((rc = alloc((void **)&tau, (size_t)d.hw16 * sizeof(float)))) return rc;
     return STCN_OK;
 }
 void Work::release() {
@@ -446,7 +448,7 @@ static int bank_reserve(stcn_engine *e, int slots) {
     float *nk, *nq, *nv;
     const size_t rows = (size_t)cap * d.hw16;
     HIPCHK(hipMalloc((void **)&nk, rows * 64 * 4));
-    HIPCHK(hipMalloc((void **)&nq, rows * 4));
+    HIPCHK(hipMalloc((void **)&nq, (rows + 64) * 4));      // +64: the read kernels fetch msq in 64-row steps
     HIPCHK(hipMalloc((void **)&nv, (size_t)e->k * rows * 512 * 4));
     if (e->n_certain > 0) {
         const size_t crow = (size_t)e->n_certain * d.hw16, orow = (size_t)e->bank_cap * d.hw16;
@@ -604,7 +606,7 @@ static int do_pass(stcn_engine *e, int idx, bool forward) {
             const int N = m_front * d.hw16;
             Scope sc(&e->prof, STCN_K_MEMREAD, e->stream, 2.0 * N * d.hw16 * 64 + 2.0 * k * d.hw16 * 50 * 512);
             memory_read_launch(e->bank_k, e->bank_msq, kf.k16, N, d.hw16, e->bank_v, (long)e->bank_cap * d.hw16 * 512, k,
-                               w.readout, (long)d.hw16 * 512, nullptr, nullptr, MemReadScratch{w.cand_v, w.cand_i}, e->stream);
+                               w.readout, (long)d.hw16 * 512, nullptr, nullptr, MemReadScratch{w.cand_v, w.cand_i, w.gmax, w.tau}, e->stream);
         }
         RC(decode(*e->model, w, e->stream, w.readout, kf.f16_thin, kf.s8, kf.s4, w.agg, d.npix));
         if (ti != end && std::abs(ti - last_ti) >= e->mem_freq) {

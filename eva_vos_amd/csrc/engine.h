@@ -77,6 +77,7 @@ struct Work {
     float *agg = nullptr;               // [k+1][npix] aggregated output of the current frame
     float *pooled = nullptr, *amap = nullptr, *attn = nullptr;   // attention read
     float *cand_v = nullptr; int32_t *cand_i = nullptr;          // memory-read chunk winners
+    float *gmax = nullptr, *tau = nullptr;                       // memory-read group maxima / thresholds
     float *vin = nullptr;               // value-encoder packed input [k][npix][8]
     Prof *prof = nullptr;
     std::vector<void *> allocs;

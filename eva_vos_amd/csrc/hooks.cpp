@@ -142,11 +142,13 @@ int stcn_test_memory_read(void *stream, const float *mk, const float *mv, const 
                           int32_t *topk_idx, float *topk_w, float *readout) {
     if (!mk || !mv || !qk || !readout || N < 50 || Q < 1 || k < 1) { set_error("stcn_test_memory_read: bad arguments (N >= 50)"); return STCN_E_INVALID; }
     hipStream_t s = (hipStream_t)stream;
-    DevBuf msq, cv, ci;
-    RC(msq.alloc(N)); RC(cv.alloc((size_t)16 * Q * 50)); RC(ci.alloc((size_t)16 * Q * 50));
+    DevBuf msq, cv, ci, gm, tau;
+    RC(msq.alloc(N + 64)); RC(cv.alloc((size_t)16 * Q * 50)); RC(ci.alloc((size_t)16 * Q * 50));
+    RC(gm.alloc((size_t)256 * Q)); RC(tau.alloc(Q));
+    HIPCHK(hipMemsetAsync(msq.p, 0, (size_t)(N + 64) * 4, s));
     rowsumsq_launch(mk, N, 64, msq.p, s);
     memory_read_launch(mk, msq.p, qk, N, Q, mv, (long)N * 512, k, readout, (long)Q * 512, topk_idx, topk_w,
-                       MemReadScratch{cv.p, reinterpret_cast<int32_t *>(ci.p)}, s);
+                       MemReadScratch{cv.p, reinterpret_cast<int32_t *>(ci.p), gm.p, tau.p}, s);
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());
     return STCN_OK;
@@ -176,7 +178,7 @@ int stcn_test_attention(void *stream, const float *mk, const float *qk, const fl
     hipStream_t s = (hipStream_t)stream;
     const int h = nh / 16, w = nw / 16;
     DevBuf msq, pooled, amap;
-    RC(msq.alloc(h * w)); RC(pooled.alloc((size_t)kk * 2 * h * w)); RC(amap.alloc((size_t)kk * 2 * h * w));
+    RC(msq.alloc(h * w + 64)); RC(pooled.alloc((size_t)kk * 2 * h * w)); RC(amap.alloc((size_t)kk * 2 * h * w));
     rowsumsq_launch(mk, h * w, 64, msq.p, s);
     attention_read_launch(mk, msq.p, qk, pos, neg, kk, h, w, pooled.p, amap.p, attn, s);
     HIPCHK(hipStreamSynchronize(s));

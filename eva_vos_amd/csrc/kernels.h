@@ -75,9 +75,9 @@ void cbam_launch(const float *x, float *out, int B, int h, int w, const CbamW &c
                  hipStream_t s);
 
 // ---------------------------------------------------------------- space-time memory read
-struct MemReadScratch { float *cand_v; int32_t *cand_i; };   // [NC][Q][50] each
+struct MemReadScratch { float *cand_v; int32_t *cand_i; float *gmax; float *tau; };   // [16][Q][50] x2, [256][Q], [Q]
 int  memread_num_chunks(int N);
-// mk [N,64], msq [N], qk [Q,64]; mv [k][N][512] with object stride mv_os; readout [k][Q][512] with
+// mk [N,64], msq [N] (+ >= 64 readable floats of padding), qk [Q,64]; mv [k][N][512] with object stride mv_os; readout [k][Q][512] with
 // row stride ro_ld (floats) and object stride ro_os.  topk_idx/topk_w optional outputs [Q,50].
 void memory_read_launch(const float *mk, const float *msq, const float *qk, int N, int Q,
                         const float *mv, long mv_os, int k, float *readout, long ro_os,

@@ -2,18 +2,20 @@
 //   affinity S = (2 mk.qk - |mk|^2 - |qk|^2)/sqrt(64)          (reference prop_net.py:80-90)
 //   per query column: top-50 over the T*H*W memory rows, softmax over the 50 (prop_net.py:53-60)
 //   readout = sum_j w_j * mv[idx_j]                             (prop_net.py:108-115)
-// The reference materialises the dense [T*HW x HW] affinity in memory and multiplies the dense matrix;
-// here S only ever lives in registers / LDS:
-//   kernel A (affinity_topk): grid = (query blocks of 64) x (memory chunks).  Each WAVE owns 16 query
-//     columns and walks its chunk in 128-row tiles: S tile = 16x16x4 fp32 MFMAs (A = memory keys
-//     straight from global/L2 as 16-B fragments, B = the wave's 16 query keys in registers, the
-//     -|mk|^2/2 row constant is the initial accumulator), the tile is transposed through a
-//     wave-private LDS slab and filtered against the wave-uniform running threshold tau[q] (the current
-//     50th best); survivors are appended by ballot/prefix (no atomics).  When a list would overflow, a
-//     wave-wide bitwise radix select keeps the best 50 and raises tau.  No workgroup barrier in the
-//     loop - the four waves only share the L1 lines of the key tile.
-//   kernel B (merge_readout): one wave per query merges the chunk winners (same select), softmaxes
-//     the 50 with wavefront reductions and gathers 50 value rows (2 KB each, NHWC bank) per object.
+// The reference materialises the dense [T*HW x HW] affinity and multiplies by the dense matrix; here S
+// only ever lives in registers.  Exact two-pass selection:
+//   pass 1 (affinity_pass<false>): S tiles on v_mfma_f32_16x16x4_f32 (A = memory keys as 16-B fragments
+//     straight from global/L2, double-buffered in registers; B = the wave's 16 query keys, resident;
+//     -|mk|^2/2 is the initial accumulator).  Every lane keeps running maxima over disjoint row groups
+//     of its query column.  The 50th largest of a query's G >= 50 group maxima is a lower bound of its
+//     true 50th largest score (they are 50 distinct elements), and a tight one (expected rank ~ 63 for
+//     G = 128 groups): threshold_kernel computes it with a wave-wide radix select.
+//   pass 2 (affinity_pass<true>): the same MFMA walk; a register-level pre-filter against the now GLOBAL
+//     threshold makes candidates rare (~1.3 x 50 per query over the whole bank), they are appended to
+//     per-(query, chunk) LDS lists with LDS atomics; an overflowing list is cut back to its best 50 by
+//     the radix select (only adversarial orderings get there).
+//   merge_readout: one wave per query merges the chunk lists, softmaxes the 50 with wavefront
+//     reductions and gathers 50 value rows (2 KB each, NHWC bank) per object.
 //   The column-constant -|qk|^2 term cancels in exp(v - v_max) and is dropped.
 #include "kernels.h"
 
@@ -22,10 +24,12 @@ namespace stcn {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 static constexpr int TOPK = 50;
-static constexpr int CAP = 128;       // per-query candidate list capacity (>= TOPK + 64)
-static constexpr int TROWS = 128;     // memory rows per tile
-static constexpr int SLD = 132;       // S slab row stride (floats): 16-B aligned, conflict-free b128 writes
-static constexpr int MAXCHUNK = 16;
+static constexpr int CAP = 128;       // per-(query, chunk) candidate list capacity (>= TOPK + 64)
+static constexpr int TROWS = 128;     // memory rows per tile of the attention read
+static constexpr int HROWS = 64;      // rows per step of the top-k passes
+static constexpr int SLD = 132;       // attention-read S slab row stride (floats)
+static constexpr int MAXCHUNK = 16;   // row chunks (grid.y) of the top-k passes
+static constexpr int NGRP = 16;       // running maxima per lane-group: 4 lane groups x 4 row blocks
 
 __device__ __forceinline__ unsigned f2key(float f) {          // order-preserving float -> uint
     const unsigned u = __float_as_uint(f);
@@ -39,14 +43,14 @@ __device__ __forceinline__ int lanes_below(unsigned long long m, int lane) {
 }
 __device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-// Keep the best TOPK of the n (<= 128) entries of a wave-owned list (values lv, payload li).
-// Returns the new threshold (the TOPK-th best value); the list is compacted to exactly TOPK entries.
+// Keep the best TOPK of the n (<= 128) entries of a wave-owned list (values lv, payload li): bitwise
+// radix select on order-preserving keys (ballot + popcount per bit), ties by list position.
+// Returns the TOPK-th best value; the list is compacted to exactly TOPK entries.
 __device__ __forceinline__ float wave_select128(float *lv, int *li, int n, int lane) {
     lds_fence();
-    const bool v0 = lane < n, v1 = lane + 64 < n;
     const float f0 = lv[lane], f1 = lv[lane + 64];
     const int i0 = li[lane], i1 = li[lane + 64];
-    const unsigned k0 = v0 ? f2key(f0) : 0u, k1 = v1 ? f2key(f1) : 0u;   // key 0 < every real key
+    const unsigned k0 = lane < n ? f2key(f0) : 0u, k1 = lane + 64 < n ? f2key(f1) : 0u;   // key 0 < every real key
     unsigned prefix = 0;
     for (int bit = 31; bit >= 0; --bit) {
         const unsigned cand = prefix | (1u << bit);
@@ -66,48 +70,39 @@ __device__ __forceinline__ float wave_select128(float *lv, int *li, int n, int l
     return key2f(prefix);
 }
 
-// One wave: S[128 rows x 16 queries] = (mk[rows] . qk[cols] - msq[rows]/2) / 4 into its LDS slab
-// Sw[q][row] (row stride SLD).  bq[kb] holds the wave's B fragments: B[k = 16kb + 4g + j][col = lane&15].
-__device__ __forceinline__ void s_tile_16q(const float *__restrict__ mk, const float *__restrict__ msq, int N,
-                                           int row0, const f32x4 (&bq)[4], float *Sw, int lane) {
+// A fragments of one 64-row step: a[rb][kb] = mk[row0 + 16 rb + (lane&15)][16 kb + 4 (lane>>4) .. +3]
+// (k-permuted like the conv kernel) and the accumulator init -|mk|^2/2 for this lane's C rows.
+struct HalfFrag { f32x4 a[4][4]; f32x4 c[4]; };
+__device__ __forceinline__ void load_half(const float *__restrict__ mk, const float *__restrict__ msq, int N,
+                                          int row0, int lane, HalfFrag &h) {
     const int g = lane >> 4, col = lane & 15;
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        f32x4 acc[4];
-        f32x4 a[4][4];
-        // issue all fragment loads of 4 row blocks (16 rows each) first
+    for (int rb = 0; rb < 4; ++rb) {
+        int r = row0 + rb * 16 + col;
+        r = r < N ? r : N - 1;
+        const float *ap = mk + (long)r * 64 + 4 * g;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) h.a[rb][kb] = *reinterpret_cast<const f32x4 *>(ap + 16 * kb);
+        // C layout 16x16: col = lane&15, row = 4*(lane>>4) + reg.  msq is padded by >= 64 readable floats.
+        h.c[rb] = *reinterpret_cast<const f32x4 *>(msq + row0 + rb * 16 + 4 * g);
+    }
+}
+// acc[rb][j] = (mk[row] . qk[col] - msq[row]/2) / 4 with row = row0 + 16 rb + 4 (lane>>4) + j, col = lane&15
+__device__ __forceinline__ void mfma_half(const HalfFrag &h, const f32x4 (&bq)[4], f32x4 (&acc)[4]) {
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) acc[rb] = h.c[rb] * -0.5f;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) {
-            int r = row0 + (half * 4 + rb) * 16 + col;      // A: row = lane&15, k = 16kb + 4g + j
-            r = r < N ? r : N - 1;
-            const float *ap = mk + (long)r * 64 + 4 * g;
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) a[rb][kb] = *reinterpret_cast<const f32x4 *>(ap + 16 * kb);
-            // C layout 16x16: col = lane&15, row = 4*(lane>>4) + reg
-            int rr = row0 + (half * 4 + rb) * 16 + 4 * g;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int r2 = rr + j < N ? rr + j : N - 1;
-                acc[rb][j] = -0.5f * msq[r2];
-            }
-        }
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-#pragma unroll
-            for (int rb = 0; rb < 4; ++rb) {
-                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rb][kb].x, bq[kb].x, acc[rb], 0, 0, 0);
-                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rb][kb].y, bq[kb].y, acc[rb], 0, 0, 0);
-                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rb][kb].z, bq[kb].z, acc[rb], 0, 0, 0);
-                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rb][kb].w, bq[kb].w, acc[rb], 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb) {
-            f32x4 v = acc[rb];
-            v.x *= 0.25f; v.y *= 0.25f; v.z *= 0.25f; v.w *= 0.25f;
-            *reinterpret_cast<f32x4 *>(&Sw[col * SLD + (half * 4 + rb) * 16 + 4 * g]) = v;
+            acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(h.a[rb][kb].x, bq[kb].x, acc[rb], 0, 0, 0);
+            acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(h.a[rb][kb].y, bq[kb].y, acc[rb], 0, 0, 0);
+            acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(h.a[rb][kb].z, bq[kb].z, acc[rb], 0, 0, 0);
+            acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(h.a[rb][kb].w, bq[kb].w, acc[rb], 0, 0, 0);
         }
     }
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) acc[rb] = acc[rb] * 0.25f;
 }
 
 __device__ __forceinline__ void load_bq(const float *__restrict__ qk, int Q, int q0, int lane, f32x4 (&bq)[4]) {
@@ -118,64 +113,102 @@ __device__ __forceinline__ void load_bq(const float *__restrict__ qk, int Q, int
     for (int kb = 0; kb < 4; ++kb) bq[kb] = *reinterpret_cast<const f32x4 *>(bp + 16 * kb);
 }
 
-template <int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void affinity_topk_kernel(
+// COLLECT == false: pass 1, writes gmax[(chunk*NGRP + 4*(lane>>4) + rb)][q] (running maxima).
+// COLLECT == true : pass 2, filters against tau[q] and writes the chunk's winners cand[chunk][q][TOPK].
+template <int WAVES, bool COLLECT>
+__global__ __launch_bounds__(64 * WAVES) void affinity_pass_kernel(
     const float *__restrict__ mk, const float *__restrict__ msq, const float *__restrict__ qk, int N, int Q,
-    int tiles_per_chunk, float *__restrict__ cand_v, int32_t *__restrict__ cand_i) {
+    int steps_per_chunk, float *__restrict__ gmax, const float *__restrict__ tau_in, float *__restrict__ cand_v,
+    int32_t *__restrict__ cand_i) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int PER_WAVE = 2 * 16 * CAP + 32;                         // floats of LDS per wave (pass 2)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float *Sw = smem + wave * (16 * SLD);                               // [16][SLD]
-    float *LV = smem + WAVES * 16 * SLD + wave * (16 * CAP);            // [16][CAP]
-    int *LI = reinterpret_cast<int *>(smem + WAVES * 16 * SLD + WAVES * 16 * CAP) + wave * (16 * CAP);
+    float *LV = smem + wave * PER_WAVE;                                 // [16][CAP]
+    int *LI = reinterpret_cast<int *>(LV + 16 * CAP);                   // [16][CAP]
+    int *CNT = LI + 16 * CAP;                                           // [16]
+    float *TAU = reinterpret_cast<float *>(CNT + 16);                   // [16]
 
     const int q0 = (blockIdx.x * WAVES + wave) * 16;
     if (q0 >= Q) return;                                                // wave-uniform; no block barriers below
     const int chunk = blockIdx.y;
-    const int tile0 = chunk * tiles_per_chunk;
-    const int ntiles_total = (N + TROWS - 1) / TROWS;
-    const int tile1 = min(ntiles_total, tile0 + tiles_per_chunk);
+    const int nsteps = (N + HROWS - 1) / HROWS;
+    const int h0 = chunk * steps_per_chunk;
+    const int h1 = min(nsteps, h0 + steps_per_chunk);
+    const int g = lane >> 4, col = lane & 15;
+    const int qcol = min(q0 + col, Q - 1);
 
     f32x4 bq[4];
     load_bq(qk, Q, q0, lane, bq);
-
-    // per-query list length / threshold live in LDS (wave-private, read back wave-uniformly)
-    int *CNT = reinterpret_cast<int *>(smem + WAVES * 16 * (SLD + 2 * CAP)) + wave * 32;
-    float *TAU = reinterpret_cast<float *>(CNT + 16);
-    if (lane < 16) { CNT[lane] = 0; TAU[lane] = -__builtin_inff(); }
-
-    for (int tile = tile0; tile < tile1; ++tile) {
-        const int row0 = tile * TROWS;
+    float tcol = -__builtin_inff();
+    f32x4 gm = {tcol, tcol, tcol, tcol};                                // pass 1: maxima per row block rb
+    if (COLLECT) {
+        tcol = tau_in[qcol];
+        if (lane < 16) { CNT[lane] = 0; TAU[lane] = tcol; }
         lds_fence();
-        s_tile_16q(mk, msq, N, row0, bq, Sw, lane);
-        lds_fence();
-        for (int j = 0; j < 16; ++j) {
-            float *lv = LV + j * CAP;
-            int *li = LI + j * CAP;
-            int cnt = __builtin_amdgcn_readfirstlane(CNT[j]);
-            float tau = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(TAU[j])));
+    }
+
+    HalfFrag cur, nxt;
+    if (h0 < h1) load_half(mk, msq, N, h0 * HROWS, lane, cur);
+    for (int h = h0; h < h1; ++h) {
+        const int row0 = h * HROWS;
+        // prefetch the next step's fragments under this step's MFMAs (clamped re-load on the last step)
+        load_half(mk, msq, N, min(h + 1, h1 - 1) * HROWS, lane, nxt);
+        f32x4 acc[4];
+        mfma_half(cur, bq, acc);
+        const bool tail = row0 + HROWS > N;
+        if (!COLLECT) {
 #pragma unroll
-            for (int step = 0; step < 2; ++step) {
-                const int row = row0 + step * 64 + lane;
-                const float v = Sw[j * SLD + step * 64 + lane];
-                bool pass = row < N && v > tau;
-                unsigned long long bal = __ballot(pass);
-                if (bal) {
-                    if (cnt + __popcll(bal) > CAP) {
-                        tau = wave_select128(lv, li, cnt, lane);
-                        cnt = TOPK;
-                        pass = pass && v > tau;
-                        bal = __ballot(pass);
-                    }
-                    if (pass) {
-                        const int p = cnt + lanes_below(bal, lane);
-                        lv[p] = v;
-                        li[p] = row;
-                    }
-                    cnt += __popcll(bal);
+            for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = (tail && row0 + rb * 16 + 4 * g + j >= N) ? -__builtin_inff() : acc[rb][j];
+                    gm[rb] = fmaxf(gm[rb], v);
                 }
+        } else {
+            bool hit = false;
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    hit |= (acc[rb][j] > tcol) && !(tail && row0 + rb * 16 + 4 * g + j >= N);
+            if (__ballot(hit)) {                                        // rare once tau is global
+                // make room: any list that could overflow in this step is cut back to its best TOPK
+                const int cn = CNT[col];
+                unsigned long long full = __ballot(cn > CAP - HROWS);
+                unsigned fq = (unsigned)((full | (full >> 16) | (full >> 32) | (full >> 48)) & 0xffffull);
+                while (fq) {
+                    const int j = __builtin_ctz(fq);
+                    fq &= fq - 1;
+                    const int c = __builtin_amdgcn_readfirstlane(CNT[j]);
+                    const float t = wave_select128(LV + j * CAP, LI + j * CAP, c, lane);
+                    if (lane == 0) { CNT[j] = TOPK; TAU[j] = fmaxf(TAU[j], t); }
+                    lds_fence();
+                }
+                tcol = TAU[col];
+                if (hit) {
+#pragma unroll
+                    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int row = row0 + rb * 16 + 4 * g + j;
+                            if (acc[rb][j] > tcol && row < N) {
+                                const int p = atomicAdd(&CNT[col], 1);
+                                LV[col * CAP + p] = acc[rb][j];
+                                LI[col * CAP + p] = row;
+                            }
+                        }
+                }
+                lds_fence();
             }
-            if (lane == 0) { CNT[j] = cnt; TAU[j] = tau; }
         }
+        cur = nxt;
+    }
+    if (!COLLECT) {
+        if (q0 + col < Q) {
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) gmax[((long)chunk * NGRP + 4 * g + rb) * Q + q0 + col] = gm[rb];
+        }
+        return;
     }
     // chunk winners -> global: cand[chunk][q][TOPK] (missing entries = -inf)
     lds_fence();
@@ -191,6 +224,47 @@ __global__ __launch_bounds__(64 * WAVES) void affinity_topk_kernel(
             cand_v[o] = lane < cnt ? lv[lane] : -__builtin_inff();
             cand_i[o] = lane < cnt ? li[lane] : 0;
         }
+    }
+}
+
+// tau[q] = TOPK-th largest of the G = NC*NGRP group maxima of query q (-inf when fewer than TOPK are finite)
+__global__ __launch_bounds__(256) void threshold_kernel(const float *__restrict__ gmax, int G, int Q,
+                                                        float *__restrict__ tau) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= Q) return;
+    unsigned k[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int gi = lane + 64 * e;
+        const float v = gi < G ? gmax[(long)gi * Q + q] : -__builtin_inff();
+        k[e] = v > -__builtin_inff() ? f2key(v) : 0u;
+    }
+    unsigned prefix = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+        const unsigned cand = prefix | (1u << bit);
+        const int c = __popcll(__ballot(k[0] >= cand)) + __popcll(__ballot(k[1] >= cand)) +
+                      __popcll(__ballot(k[2] >= cand)) + __popcll(__ballot(k[3] >= cand));
+        if (c >= TOPK) prefix = cand;
+    }
+    // prefix == 0: fewer than TOPK finite maxima -> no usable bound.  The bound must stay BELOW the
+    // TOPK-th best (the filter keeps v > tau): step one key down.
+    if (lane == 0) tau[q] = prefix == 0u ? -__builtin_inff() : key2f(prefix - 1u);
+}
+
+// full 128-row tile into a slab Sw[q][row] with stride SLD (used by the attention read)
+__device__ __forceinline__ void s_tile_16q(const float *__restrict__ mk, const float *__restrict__ msq, int N,
+                                           int row0, const f32x4 (&bq)[4], float *Sw, int lane) {
+    const int g = lane >> 4, col = lane & 15;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        HalfFrag h;
+        load_half(mk, msq, N, row0 + half * HROWS, lane, h);
+        f32x4 acc[4];
+        mfma_half(h, bq, acc);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+            *reinterpret_cast<f32x4 *>(&Sw[col * SLD + (half * 4 + rb) * 16 + 4 * g]) = acc[rb];
     }
 }
 
@@ -282,28 +356,38 @@ __global__ __launch_bounds__(256) void merge_readout_kernel(const float *__restr
 }
 
 int memread_num_chunks(int N) {
-    const int tiles = (N + TROWS - 1) / TROWS;
-    return tiles < MAXCHUNK ? tiles : MAXCHUNK;
+    const int steps = (N + HROWS - 1) / HROWS;
+    return steps < MAXCHUNK ? steps : MAXCHUNK;
 }
 
 void memory_read_launch(const float *mk, const float *msq, const float *qk, int N, int Q, const float *mv,
                         long mv_os, int k, float *readout, long ro_os, int32_t *topk_idx, float *topk_w,
                         MemReadScratch scr, hipStream_t s) {
-    const int tiles = (N + TROWS - 1) / TROWS;
-    const int NC = memread_num_chunks(N);
-    const int tpc = (tiles + NC - 1) / NC;
-    const int NCeff = (tiles + tpc - 1) / tpc;
     constexpr int WAVES = 4;
-    const size_t lds = (size_t)WAVES * (16 * (SLD + 2 * CAP) + 32) * sizeof(float);
+    const int steps = (N + HROWS - 1) / HROWS;
+    const int qblocks = (Q + 16 * WAVES - 1) / (16 * WAVES);
+    // chunks: >= 4 so that G = 16*NC >= 64 group maxima exist (tight, valid threshold), and enough
+    // workgroups to cover the 256 CUs a few times over
+    int NC = (768 + qblocks - 1) / qblocks;
+    if (NC < 4) NC = 4;
+    if (NC > MAXCHUNK) NC = MAXCHUNK;
+    if (NC > steps) NC = steps;
+    const int spc = (steps + NC - 1) / NC;
+    const int NCeff = (steps + spc - 1) / spc;
+    const size_t lds2 = (size_t)WAVES * (2 * 16 * CAP + 32) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&affinity_topk_kernel<WAVES>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&affinity_pass_kernel<WAVES, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
         attr_set = true;
     }
-    const dim3 grid((Q + 16 * WAVES - 1) / (16 * WAVES), NCeff);
-    hipLaunchKernelGGL((affinity_topk_kernel<WAVES>), grid, dim3(64 * WAVES), lds, s, mk, msq, qk, N, Q, tpc,
-                       scr.cand_v, scr.cand_i);
+    const dim3 grid(qblocks, NCeff);
+    float *gmax = scr.gmax, *tau = scr.tau;
+    hipLaunchKernelGGL((affinity_pass_kernel<WAVES, false>), grid, dim3(64 * WAVES), 0, s, mk, msq, qk, N, Q, spc, gmax,
+                       (const float *)nullptr, (float *)nullptr, (int32_t *)nullptr);
+    hipLaunchKernelGGL(threshold_kernel, dim3((Q + 3) / 4), dim3(256), 0, s, gmax, NCeff * NGRP, Q, tau);
+    hipLaunchKernelGGL((affinity_pass_kernel<WAVES, true>), grid, dim3(64 * WAVES), lds2, s, mk, msq, qk, N, Q, spc,
+                       (float *)nullptr, tau, scr.cand_v, scr.cand_i);
     hipLaunchKernelGGL(merge_readout_kernel, dim3((Q + 3) / 4), dim3(256), 0, s, scr.cand_v, scr.cand_i, NCeff, Q,
                        mv, mv_os, k, readout, ro_os, topk_idx, topk_w);
 }
@@ -426,7 +510,7 @@ void attention_read_launch(const float *mk, const float *msq, const float *qk, c
     hipLaunchKernelGGL(area_pool16_kernel, dim3((unsigned)(((long)nch * hw + 255) / 256)), dim3(256), 0, s, pos, neg,
                        kk, h, w, pooled);
     const size_t lds = (size_t)(16 * SLD + 2 * 16 * 64 + 16 * nch * 64) * sizeof(float);
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&attention_softmax_kernel),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&attention_softmax_kernel),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(attention_softmax_kernel, dim3((hw + 15) / 16), dim3(64), lds, s, mk, msq, qk, hw, pooled, nch,
                        amap);
