@@ -86,12 +86,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     torch.set_grad_enabled(False)
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (there is no CPU fallback of the product)"
+    # STCN_BENCH_DEVICE / STCN_BENCH_BACKEND exist only to exercise the multi-rank path on a 1-GPU box
+    # (all ranks on one device, gloo); the driver's runs use one GPU per rank and RCCL ("nccl").
+    local = int(os.environ.get("STCN_BENCH_DEVICE", local))
+    backend = os.environ.get("STCN_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+    red_dev = "cuda" if backend == "nccl" else "cpu"
 
     from eva_vos_amd import metrics, shard, synth
     from eva_vos_amd.params import FusionNet, PropagationNetwork
@@ -110,6 +118,9 @@ def main():
 
     # one HIP stream per in-flight video; engines are bound to the stream they are created under
     S = max(1, min(a.streams, a.steps))
+    # engine knob: key-encoder look-ahead on a side stream helps a single video in flight (+6 %) but only
+    # adds contention when several videos already overlap
+    os.environ.setdefault("STCN_LOOKAHEAD", "0" if S > 1 else "2")
     streams = [torch.cuda.Stream() for _ in range(S)] if S > 1 else [torch.cuda.current_stream()]
     def make(lane):
         with torch.cuda.stream(streams[lane]):
@@ -178,7 +189,7 @@ def main():
             t_roof += time.perf_counter() - tr
             roof_frames += e.stats()["frames"]
             for cls, v in e.kernel_profile().items():
-                acc = prof.setdefault(cls, dict(ms=0.0, launches=0, flops=0.0))
+                acc = prof.setdefault(cls, dict(ms=0.0, launches=0, flops=0.0, bytes=0.0))
                 for k_ in acc:
                     acc[k_] += v[k_]
             del e
@@ -193,9 +204,9 @@ def main():
 
     # whole-job numbers: max time over ranks, frames summed over ranks
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        ff = torch.tensor([frames], dtype=torch.float64, device="cuda")
+        ff = torch.tensor([frames], dtype=torch.float64, device=red_dev)
         dist.all_reduce(ff, op=dist.ReduceOp.SUM)
         dt_all, frames_all = float(tt.item()), float(ff.item())
     else:
@@ -219,6 +230,7 @@ def main():
                                    f"STCN propagate: fresh engine, interact(mask,0), T={T} frames/video, "
                                    f"mem_freq={a.mem_freq}, top_k=50; one video per step per GPU",
                        "frames_per_step": T - 1, "videos_per_gpu": a.steps, "sharding": f"videos x{world}", "streams_per_gpu": S,
+                       "key_lookahead": int(os.environ["STCN_LOOKAHEAD"]),
                        "weights": "synthetic recipe seed 0 (no checkpoints offline)"},
             "ms_per_frame": 1e3 * dt_all / (frames_all / world),
             "jf_rows_rank_J_F_JF": rows.round(4).tolist(),
@@ -235,6 +247,14 @@ def main():
                                "flop_per_launch_avg": conv["flops"] / max(conv["launches"], 1)}
             tot_ms = sum(v["ms"] for v in prof.values())
             out["kernel_time_share"] = {c: round(v["ms"] / tot_ms, 4) for c, v in prof.items() if v["ms"] > 0}
+            # HBM-side bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate runs)
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+                out["roofline"]["traffic"] = pmc["conv_gemm_traffic_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc passes of this workload at T=30)"
+            except OSError:
+                pass
+            out["roofline"]["algorithmic_bytes_per_launch"] = conv["bytes"] / max(conv["launches"], 1)
             out["roofline"]["leg"] = f"{max(1, a.roof_steps)} video(s), 1 stream, HIP events per launch"
             out["device_busy_frac_roofline_leg"] = tot_ms * 1e-3 / t_roof
             out["algorithmic_gflop_per_frame"] = sum(v["flops"] for v in prof.values()) / roof_frames / 1e9

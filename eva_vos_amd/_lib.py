@@ -49,6 +49,7 @@ PROTOTYPES = {
     "stcn_engine_set_profiling": (_I, [_P, _I]),
     "stcn_get_kernel_ms": (_I, [_P, C.POINTER(_F), C.POINTER(C.c_int32)]),
     "stcn_get_kernel_flops": (_I, [_P, C.POINTER(_D)]),
+    "stcn_get_kernel_bytes": (_I, [_P, C.POINTER(_D)]),
 }
 
 _lib = None

@@ -188,11 +188,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvP p, const int
     const int nk = kt1 - kt0;
     if (nk > 0) {
         gload_all(kt0, I0{});
+        gload_all(kt0 + 1, I1{});                  // tile 1 -> set 1 (past the K range: zeros / last tile);
+                                                   // issued before the first write-back so both latencies overlap
 #pragma unroll
         for (int i = 0; i < WM; ++i) s_a(i, 0, I0{});
 #pragma unroll
         for (int i = 0; i < WN; ++i) s_b(i, 0, I0{});
-        gload_all(kt0 + 1, I1{});                  // tile 1 -> set 1 (past the K range: zeros / last tile)
     }
     __syncthreads();
 
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvP p, const int
             float v = acc[r] + bv;
             long yo = (long)m * p.N + n;
             if (needb) {
-                const int b = m / ohw;
+                const int b = p.B == 1 ? 0 : m / ohw;
                 const long po = (long)(m - b * ohw) * p.N + n;
                 if (p.res) v += p.res[(long)b * p.res_bs + po];
                 if (p.y_bs) yo = (long)b * p.y_bs + po;
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(256) void conv_reduce_kernel(const ConvP p) {
         if (p.bias) v += *reinterpret_cast<const f32x4 *>(p.bias + n);
         long yo = e;
         if (p.res || p.y_bs) {
-            const int b = m / ohw;
+            const int b = p.B == 1 ? 0 : m / ohw;
             const long po = (long)(m - b * ohw) * p.N + n;
             if (p.res) v += *reinterpret_cast<const f32x4 *>(p.res + (long)b * p.res_bs + po);
             if (p.y_bs) yo = (long)b * p.y_bs + po;

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace stcn {
@@ -21,7 +22,7 @@ const char *get_error() { return g_err; }
 
 // ---------------------------------------------------------------------------------------------- Prof
 void Prof::reset() {
-    for (int i = 0; i < STCN_K_COUNT; ++i) { flops[i] = 0; launches[i] = 0; }
+    for (int i = 0; i < STCN_K_COUNT; ++i) { flops[i] = 0; bytes[i] = 0; launches[i] = 0; }
     for (auto &e : events) { pool.push_back(e.a); pool.push_back(e.b); }
     events.clear();
 }
@@ -247,6 +248,9 @@ int run_conv(const Model &m, Work &w, hipStream_t s, const char *name, const flo
     while (p.splitk > 1 && (size_t)p.splitk * p.M * p.N > w.splitk_floats) --p.splitk;
     p.partial = w.splitk;
     const double fl = 2.0 * p.M * p.N * (double)(cw.kh * cw.kw * cw.cin);
+    if (w.prof)   // algorithmic bytes: input(s), weights, output and residual once each
+        w.prof->bytes[STCN_K_CONV] += 4.0 * ((double)p.x0_bytes / 4 + (double)p.x1_bytes / 4 + (double)cw.cout * cw.K +
+                                             (double)p.M * p.N * (res ? 2 : 1));
     Scope sc(w.prof, STCN_K_CONV, s, fl);
     conv_launch(p, s);
     return STCN_OK;
@@ -476,6 +480,19 @@ static int engine_alloc_common(stcn_engine *e) {
     RC(eng_alloc(e, (void **)&e->neg, (size_t)(e->k + 1) * d.npix * 4));
     RC(e->work.init(d.nh, d.nw, e->k));
     e->work.prof = &e->prof;
+    // Look-ahead is only used when no cache slot is ever recycled (T <= slots): the key encoder of the
+    // next frames then runs on a side stream concurrently with the memory-read / decoder chain.
+    const char *la = getenv("STCN_LOOKAHEAD");
+    e->lookahead = la ? atoi(la) : 2;
+    if (e->T > e->n_slots) e->lookahead = 0;
+    if (e->lookahead > 0) {
+        HIPCHK(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+        RC(e->work_side.init(d.nh, d.nw, 1));
+        e->work_side.prof = &e->prof;
+        e->key_ready.assign(e->T, nullptr);
+        for (int t = 0; t < e->T; ++t) HIPCHK(hipEventCreateWithFlags(&e->key_ready[t], hipEventDisableTiming));
+    }
+    e->key_pending.assign(e->T, 0);
     return STCN_OK;
 }
 
@@ -513,6 +530,9 @@ int stcn_engine_create(const stcn_model *m, int T, int H, int W, int k, int mem_
 int stcn_engine_destroy(stcn_engine *e) {
     if (!e) return STCN_OK;
     if (e->stream) (void)hipStreamSynchronize(e->stream); else (void)hipDeviceSynchronize();
+    if (e->side) { (void)hipStreamSynchronize(e->side); (void)hipStreamDestroy(e->side); }
+    for (hipEvent_t ev : e->key_ready) if (ev) (void)hipEventDestroy(ev);
+    e->work_side.release();
     for (void *p : e->allocs) (void)hipFree(p);
     if (e->bank_k) { (void)hipFree(e->bank_k); (void)hipFree(e->bank_msq); (void)hipFree(e->bank_v); }
     e->work.release();
@@ -533,6 +553,7 @@ int stcn_engine_clone(const stcn_engine *src, float *prob_dev, uint8_t *masks_de
     if (rc) { stcn_engine_destroy(e); return rc; }
     const Dims &d = e->d;
     HIPCHK(hipStreamSynchronize(src->stream));
+    if (src->side) HIPCHK(hipStreamSynchronize(src->side));
     HIPCHK(hipMemcpyAsync(e->images4, src->images4, (size_t)e->T * d.npix * 16, hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(e->cache, src->cache, (size_t)e->n_slots * e->slot_floats * 4, hipMemcpyDeviceToDevice, e->stream));
     e->slot_of = src->slot_of; e->n_cached = src->n_cached;
@@ -553,19 +574,36 @@ int stcn_engine_clone(const stcn_engine *src, float *prob_dev, uint8_t *masks_de
     return STCN_OK;
 }
 
-// key features of frame ti (cached; inference_core.py:115-124)
+// key features of frame ti (cached; inference_core.py:115-124).  enqueue_key() starts the encoder for
+// a missing frame (on the side stream when look-ahead is on); ensure_key() additionally orders the main
+// stream behind it.
+static int enqueue_key(stcn_engine *e, int ti) {
+    if (e->slot_of[ti] >= 0) return STCN_OK;
+    if (e->n_cached >= e->n_slots) {                         // flush-all policy of the reference
+        std::fill(e->slot_of.begin(), e->slot_of.end(), -1);
+        e->n_cached = 0;
+    }
+    const int slot = e->n_cached++;
+    e->slot_of[ti] = slot;
+    const SlotPtrs p = slot_ptrs(e, slot);
+    KeyOut ko{p.k16, p.msq, p.f16_thin, p.f16, p.s8, p.s4, nullptr, nullptr};
+    const float *img = e->images4 + (size_t)ti * e->d.npix * 4;
+    if (e->lookahead > 0) {
+        RC(encode_key(*e->model, e->work_side, e->side, img, ko));
+        HIPCHK(hipEventRecord(e->key_ready[ti], e->side));
+        e->key_pending[ti] = 1;
+    } else {
+        RC(encode_key(*e->model, e->work, e->stream, img, ko));
+    }
+    e->stats.key_miss++;
+    return STCN_OK;
+}
+
 static int ensure_key(stcn_engine *e, int ti, SlotPtrs *out) {
-    if (e->slot_of[ti] < 0) {
-        if (e->n_cached >= e->n_slots) {                     // flush-all policy of the reference
-            std::fill(e->slot_of.begin(), e->slot_of.end(), -1);
-            e->n_cached = 0;
-        }
-        const int slot = e->n_cached++;
-        e->slot_of[ti] = slot;
-        const SlotPtrs p = slot_ptrs(e, slot);
-        KeyOut ko{p.k16, p.msq, p.f16_thin, p.f16, p.s8, p.s4, nullptr, nullptr};
-        RC(encode_key(*e->model, e->work, e->stream, e->images4 + (size_t)ti * e->d.npix * 4, ko));
-        e->stats.key_miss++;
+    RC(enqueue_key(e, ti));
+    if (e->key_pending[ti]) {
+        HIPCHK(hipStreamWaitEvent(e->stream, e->key_ready[ti], 0));
+        e->key_pending[ti] = 0;
     }
     *out = slot_ptrs(e, e->slot_of[ti]);
     return STCN_OK;
@@ -600,6 +638,7 @@ static int do_pass(stcn_engine *e, int idx, bool forward) {
     const long prs = (long)T * d.npix;                      // prob row stride
     Work &w = e->work;
     for (int ti = idx + step; ti != closest; ti += step) {
+        for (int a = 1, tj = ti + step; a <= e->lookahead && tj != closest; ++a, tj += step) RC(enqueue_key(e, tj));
         SlotPtrs kf;
         RC(ensure_key(e, ti, &kf));
         {
@@ -706,6 +745,11 @@ int stcn_get_kernel_ms(const stcn_engine *e, float *ms, int32_t *launches) {
 int stcn_get_kernel_flops(const stcn_engine *e, double *flops) {
     if (!e || !flops) return STCN_E_INVALID;
     for (int i = 0; i < STCN_K_COUNT; ++i) flops[i] = e->prof.flops[i];
+    return STCN_OK;
+}
+int stcn_get_kernel_bytes(const stcn_engine *e, double *bytes) {
+    if (!e || !bytes) return STCN_E_INVALID;
+    for (int i = 0; i < STCN_K_COUNT; ++i) bytes[i] = e->prof.bytes[i];
     return STCN_OK;
 }
 

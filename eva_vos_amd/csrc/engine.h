@@ -52,6 +52,7 @@ struct Dims {
 struct Prof {
     bool on = false;
     double flops[STCN_K_COUNT] = {0};
+    double bytes[STCN_K_COUNT] = {0};     // algorithmic HBM bytes (each operand once)
     int launches[STCN_K_COUNT] = {0};
     struct Ev { int cls; hipEvent_t a, b; };
     std::vector<Ev> events;
@@ -122,6 +123,12 @@ struct stcn_engine {
     std::set<int> interacted;
     float *mask_pad = nullptr, *pos = nullptr, *neg = nullptr;   // [k+1][npix] each
     stcn::Work work;
+    // key-encoder look-ahead: frames ahead of the decode chain are encoded on a side stream
+    hipStream_t side = nullptr;
+    stcn::Work work_side;
+    std::vector<hipEvent_t> key_ready;   // per frame: recorded on `side` after its encode_key
+    std::vector<char> key_pending;       // per frame: main stream has not yet waited on key_ready
+    int lookahead = 0;
     stcn::Prof prof;
     stcn_stats stats{};
     std::vector<void *> allocs;

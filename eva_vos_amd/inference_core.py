@@ -134,10 +134,11 @@ class InferenceCore:
     def kernel_profile(self) -> dict:
         """Per-kernel-class device ms / launches / algorithmic FLOP of the last interact()."""
         n = len(_lib.K_CLASSES)
-        ms, ln, fl = (C.c_float * n)(), (C.c_int32 * n)(), (C.c_double * n)()
+        ms, ln, fl, by = (C.c_float * n)(), (C.c_int32 * n)(), (C.c_double * n)(), (C.c_double * n)()
         _lib.check(_lib.lib().stcn_get_kernel_ms(self._engine, ms, ln))
         _lib.check(_lib.lib().stcn_get_kernel_flops(self._engine, fl))
-        return {c: dict(ms=ms[i], launches=ln[i], flops=fl[i]) for i, c in enumerate(_lib.K_CLASSES)}
+        _lib.check(_lib.lib().stcn_get_kernel_bytes(self._engine, by))
+        return {c: dict(ms=ms[i], launches=ln[i], flops=fl[i], bytes=by[i]) for i, c in enumerate(_lib.K_CLASSES)}
 
     def __deepcopy__(self, memo):
         new = object.__new__(InferenceCore)

@@ -153,6 +153,8 @@ int stcn_engine_set_profiling(stcn_engine *e, int on);
 int stcn_get_kernel_ms(const stcn_engine *e, float *ms /*[STCN_K_COUNT]*/, int32_t *launches /*[STCN_K_COUNT]*/);
 /* Algorithmic FLOP (2 x MAC) issued per kernel class by the last interact(). */
 int stcn_get_kernel_flops(const stcn_engine *e, double *flops /*[STCN_K_COUNT]*/);
+/* Algorithmic HBM bytes (every operand of every launch once; conv class only) of the last interact(). */
+int stcn_get_kernel_bytes(const stcn_engine *e, double *bytes /*[STCN_K_COUNT]*/);
 
 #ifdef __cplusplus
 }

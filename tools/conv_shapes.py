@@ -54,17 +54,34 @@ def main():
     torch.cuda.init()
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     tot_ms = tot_fl = 0.0
+    sweep = "--sweep" in sys.argv
+    sweep_gain = [0.0]
     print(f"{'layer':30s} {'M':>7s} {'N':>5s} {'K':>6s} {'ms':>8s} {'TFLOP/s':>8s} {'ms/frame':>9s}")
     for name, B, H, W, Cin, Cout, K, st, cnt in SHAPES:
         if only and only not in name:
             continue
         ms, fl = C.c_float(), C.c_double()
         _lib.check(lib.stcn_bench_conv(s, B, H, W, Cin, Cout, K, K, st, K // 2, splitk, iters, C.byref(ms), C.byref(fl)))
+        if sweep:
+            best = (ms.value, 0)
+            res = []
+            for sk in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16):
+                if sk > max(1, (K * K * Cin + 31) // 32 // 2):
+                    break
+                m2 = C.c_float()
+                _lib.check(lib.stcn_bench_conv(s, B, H, W, Cin, Cout, K, K, st, K // 2, sk, iters, C.byref(m2), C.byref(fl)))
+                res.append(f"{sk}:{m2.value*1e3:.0f}")
+                if m2.value < best[0]:
+                    best = (m2.value, sk)
+            print(f"    auto {ms.value*1e3:.0f}us | " + " ".join(res) + f" | best sk={best[1]} {best[0]*1e3:.0f}us ({(1 - best[0]/ms.value)*100:.0f}% better)")
+            sweep_gain[0] += (ms.value - best[0]) * cnt
         OH, OW = (H + 2 * (K // 2) - K) // st + 1, (W + 2 * (K // 2) - K) // st + 1
         tf = fl.value / (ms.value * 1e-3) / 1e12
         tot_ms += ms.value * cnt
         tot_fl += fl.value * cnt
         print(f"{name:30s} {B*OH*OW:7d} {Cout:5d} {K*K*Cin:6d} {ms.value:8.4f} {tf:8.1f} {ms.value*cnt:9.3f}")
+    if sweep:
+        print(f"split-K sweep: {sweep_gain[0]:.3f} ms/frame recoverable")
     print(f"weighted per R1 frame: {tot_ms:.3f} ms, {tot_fl/1e9:.1f} GFLOP, {tot_fl/tot_ms/1e9:.1f} TFLOP/s")
 
 
