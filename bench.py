@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=854)
     ap.add_argument("--mem-freq", type=int, default=5)
+    ap.add_argument("--objects", type=int, default=1, help="k>1: multi-object engine via the scribble/(k+1)-channel path (config 3)")
     ap.add_argument("--cpu-frames", type=int, default=40, help="frames of the bounded CPU-oracle sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip the roofline leg (roofline = null)")
     ap.add_argument("--roof-steps", type=int, default=1, help="videos of the profiled single-stream roofline leg")
@@ -112,9 +113,14 @@ def main():
 
     T, H, W = a.frames, a.height, a.width
     img = synth.synthetic_clip(T, H, W).cuda()
-    gt = synth.synthetic_mask(T, H, W, 1)
-    mask0 = gt[:, 0].clone()
-    mask_mid = gt[:, T // 2].clone()
+    K_OBJ = a.objects
+    gt = synth.synthetic_mask(T, H, W, K_OBJ)
+
+    def as_input(m):         # k == 1: [1,1,H,W] without bg row; k > 1: bg row first + scribble=True (reference semantics)
+        return m.clone() if K_OBJ == 1 else torch.cat([1 - m.sum(0, keepdim=True).clamp(0, 1), m], 0)
+
+    mask0 = as_input(gt[:, 0])
+    mask_mid = as_input(gt[:, T // 2])
 
     # one HIP stream per in-flight video; engines are bound to the stream they are created under
     S = max(1, min(a.streams, a.steps))
@@ -124,16 +130,16 @@ def main():
     streams = [torch.cuda.Stream() for _ in range(S)] if S > 1 else [torch.cuda.current_stream()]
     def make(lane):
         with torch.cuda.stream(streams[lane]):
-            return InferenceCore(prop, fuse, img, 1, mem_freq=a.mem_freq)
+            return InferenceCore(prop, fuse, img, K_OBJ, mem_freq=a.mem_freq)
 
     warm = [make(i % S) for i in range(a.warmup)]
     timed = [make(j % S) for j in range(a.steps)]           # video j runs on lane j % S
     torch.cuda.synchronize()
     for i, e in enumerate(warm):
         with torch.cuda.stream(streams[i % S]):
-            e.interact(mask0, 0)
+            e.interact(mask0, 0, scribble=K_OBJ > 1)
             if a.r2:
-                e.interact(mask_mid, T // 2)
+                e.interact(mask_mid, T // 2, scribble=K_OBJ > 1)
     torch.cuda.synchronize()
     del warm
 
@@ -149,7 +155,7 @@ def main():
         with torch.cuda.stream(streams[lane]):
             for j in range(lane, len(timed), S):
                 e = timed[j]
-                out = e.interact(mask, idx)
+                out = e.interact(mask, idx, scribble=K_OBJ > 1)
                 fr += e.stats()["frames"]
         return fr, out
 
@@ -179,12 +185,14 @@ def main():
     if not a.no_profile:
         prof = {}
         roof_frames, t_roof = 0, 0.0
+        la_saved = os.environ.get("STCN_LOOKAHEAD")
+        os.environ["STCN_LOOKAHEAD"] = "0"            # solo launches only: no side-stream overlap in this leg
         for _ in range(max(1, a.roof_steps)):
-            e = InferenceCore(prop, fuse, img, 1, mem_freq=a.mem_freq)
+            e = InferenceCore(prop, fuse, img, K_OBJ, mem_freq=a.mem_freq)
             e.set_profiling(True)
             torch.cuda.synchronize()
             tr = time.perf_counter()
-            e.interact(mask0, 0)
+            e.interact(mask0, 0, scribble=K_OBJ > 1)
             torch.cuda.synchronize()
             t_roof += time.perf_counter() - tr
             roof_frames += e.stats()["frames"]
@@ -193,6 +201,7 @@ def main():
                 for k_ in acc:
                     acc[k_] += v[k_]
             del e
+        os.environ["STCN_LOOKAHEAD"] = la_saved
 
     r2 = None
     if a.r2:
@@ -214,7 +223,7 @@ def main():
 
     # per-video J&F rows of the last video of each rank, gathered once (the path's only exchange step)
     lw, uw, lh, uh = timed[-1].pad
-    sc = metrics.sequence_scores(gt[0, :, 0].numpy() > 0.5, last > 0, every=max(1, T // 6))
+    sc = metrics.sequence_scores(gt[0, :, 0].numpy() > 0.5, last == 1, every=max(1, T // 6))
     row = np.array([[rank, sc[1:, 1].mean(), sc[1:, 2].mean(), sc[1:, 3].mean()]], np.float32)
     rows = shard.gather_rows(row, 4)
 
@@ -226,7 +235,7 @@ def main():
             "ms_per_step": 1e3 * dt_all / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"DAVIS-17-val-shaped {H}x{W} (padded {timed[0].nh}x{timed[0].nw}) single-object "
+            "config": {"workload": f"DAVIS-17-val-shaped {H}x{W} (padded {timed[0].nh}x{timed[0].nw}) {'single' if K_OBJ == 1 else K_OBJ}-object "
                                    f"STCN propagate: fresh engine, interact(mask,0), T={T} frames/video, "
                                    f"mem_freq={a.mem_freq}, top_k=50; one video per step per GPU",
                        "frames_per_step": T - 1, "videos_per_gpu": a.steps, "sharding": f"videos x{world}", "streams_per_gpu": S,

@@ -21,6 +21,8 @@
 //   * split-K over K tiles with an fp32 slab workspace + a vectorised reduce/epilogue kernel; the
 //     host picks the split so that tiles*split fills the 256 CUs in whole rounds.
 //   * XCD-aware block remap: each XCD (own L2) gets a contiguous range of (m-tile, n-tile) pairs.
+#include <hip/hip_ext.h>
+
 #include <type_traits>
 
 #include "kernels.h"
@@ -330,7 +332,7 @@ size_t conv_workspace_floats(const ConvP &p) {
     return p.splitk > 1 ? (size_t)p.splitk * p.M * p.N : 0;
 }
 
-void conv_launch(const ConvP &p, hipStream_t s) {
+void conv_launch(const ConvP &p, hipStream_t s, hipEvent_t *ev_gemm, hipEvent_t *ev_red) {
     const bool narrow = narrow_variant(p);
     const int BM = narrow ? 128 : 64, BN = narrow ? 32 : 64;
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
@@ -340,8 +342,10 @@ void conv_launch(const ConvP &p, hipStream_t s) {
     const size_t lds = (size_t)2 * (BM + BN) * LDT * sizeof(float);
     const dim3 grid(ntile * p.splitk);
     const bool smallc = (p.Cin % 32) != 0 || (p.x1 && (p.c0 % 32) != 0) || p.KH * p.KW > 32;
-#define STCN_LAUNCH(WM_, WN_, SC_, RL_) \
-    hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, SC_, RL_>), grid, dim3(256), lds, s, p, tiles_n, ntile, per)
+    hipEvent_t e0 = ev_gemm ? ev_gemm[0] : nullptr, e1 = ev_gemm ? ev_gemm[1] : nullptr;
+#define STCN_LAUNCH(WM_, WN_, SC_, RL_)                                                                          \
+    hipExtLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, SC_, RL_>), grid, dim3(256), lds, s, e0, e1, 0, p, tiles_n, \
+                          ntile, per)
     const int key = (narrow ? 4 : 0) | (smallc ? 2 : 0) | (p.relu_in ? 1 : 0);
     switch (key) {
         case 0: STCN_LAUNCH(2, 2, false, false); break;
@@ -358,7 +362,8 @@ void conv_launch(const ConvP &p, hipStream_t s) {
         const long total4 = (long)p.M * p.N / 4;
         long blocks = (total4 + 255) / 256;
         if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(conv_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
+        hipExtLaunchKernelGGL(conv_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, ev_red ? ev_red[0] : nullptr,
+                              ev_red ? ev_red[1] : nullptr, 0, p);
     }
 }
 

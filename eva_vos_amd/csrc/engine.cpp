@@ -37,6 +37,17 @@ void Prof::begin(int cls, hipStream_t s) {
     (void)hipEventRecord(e.a, s);
     events.push_back(e);
 }
+hipEvent_t *Prof::attach(int cls) {
+    launches[cls]++;
+    if (!on) return nullptr;
+    Ev e; e.cls = cls;
+    for (hipEvent_t *p : {&e.a, &e.b}) {
+        if (!pool.empty()) { *p = pool.back(); pool.pop_back(); }
+        else (void)hipEventCreate(p);
+    }
+    events.push_back(e);
+    return &events.back().a;
+}
 void Prof::end(hipStream_t s) {
     if (!on) return;
     (void)hipEventRecord(events.back().b, s);
@@ -251,8 +262,13 @@ int run_conv(const Model &m, Work &w, hipStream_t s, const char *name, const flo
     if (w.prof)   // algorithmic bytes: input(s), weights, output and residual once each
         w.prof->bytes[STCN_K_CONV] += 4.0 * ((double)p.x0_bytes / 4 + (double)p.x1_bytes / 4 + (double)cw.cout * cw.K +
                                              (double)p.M * p.N * (res ? 2 : 1));
-    Scope sc(w.prof, STCN_K_CONV, s, fl);
-    conv_launch(p, s);
+    hipEvent_t *eg = nullptr, *er = nullptr;
+    if (w.prof) {
+        w.prof->flops[STCN_K_CONV] += fl;
+        eg = w.prof->attach(STCN_K_CONV);
+        if (p.splitk > 1) er = w.prof->attach(STCN_K_CONV_REDUCE);
+    }
+    conv_launch(p, s, eg, er);
     return STCN_OK;
 }
 

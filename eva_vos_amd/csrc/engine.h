@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <deque>
 #include <map>
 #include <set>
 #include <string>
@@ -54,11 +55,13 @@ struct Prof {
     double flops[STCN_K_COUNT] = {0};
     double bytes[STCN_K_COUNT] = {0};     // algorithmic HBM bytes (each operand once)
     int launches[STCN_K_COUNT] = {0};
-    struct Ev { int cls; hipEvent_t a, b; };
-    std::vector<Ev> events;
+    struct Ev { int cls; hipEvent_t a, b; };    // a, b contiguous: attach() hands out &a as hipEvent_t[2]
+    std::deque<Ev> events;                      // deque: attach() returns pointers into it
     std::vector<hipEvent_t> pool;
     void reset();
     void begin(int cls, hipStream_t s);
+    // register an event pair that the launch itself will fill (hipExtLaunchKernelGGL); null when off
+    hipEvent_t *attach(int cls);
     void end(hipStream_t s);
     int collect(float *ms);
     ~Prof();

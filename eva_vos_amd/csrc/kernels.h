@@ -30,7 +30,9 @@ struct ConvP {
 };
 // picks the tile variant; returns the split-K it used
 int  conv_choose_splitk(const ConvP &p);
-void conv_launch(const ConvP &p, hipStream_t s);
+// ev_gemm / ev_red: optional {start, stop} event pairs attached to the GEMM / reduce dispatches themselves
+// (hipExtLaunchKernelGGL: kernel begin/end timestamps, no extra barrier packets)
+void conv_launch(const ConvP &p, hipStream_t s, hipEvent_t *ev_gemm = nullptr, hipEvent_t *ev_red = nullptr);
 size_t conv_workspace_floats(const ConvP &p);
 
 // Cout == 1 convolution (decoder.pred, FusionNet.final_conv): one dot product per output pixel.

@@ -105,3 +105,24 @@ def test_full_resolution_round_trip_properties(nets):
     assert np.array_equal(am.astype(np.uint8), outs[0][0])
     frac = outs[0][0][1:].mean()
     assert 0.05 < frac < 0.95
+
+
+def test_config3_multi_object_full_bank_properties(nets):
+    """BASELINE config 3 shape (480p, k=3 through the scribble/(k+1)-channel path, mem_freq=1: every frame
+    enters the bank): bank growth, probability simplex, determinism, object exclusivity of the masks."""
+    T, H, W, k = 9, 480, 854, 3
+    img, msk = synth.synthetic_clip(T, H, W), synth.synthetic_mask(T, H, W, k)
+    m0 = torch.cat([1 - msk[:, 0].sum(0, keepdim=True).clamp(0, 1), msk[:, 0]], 0)
+    outs = []
+    for _ in range(2):
+        core = make_core(nets)(img, k, 1)
+        out = core.interact(m0, 0, scribble=True)
+        outs.append((out.copy(), core.prob.clone(), core.stats()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    s = outs[0][2]
+    assert s["frames"] == T - 1 and s["bank_fwd"] == T - 1 and s["value_enc"] == T - 1   # mem_freq=1: all but the last frame
+    prob = outs[0][1]
+    assert prob.shape == (k + 1, T, 1, 480, 864)
+    assert (prob[:, 1:].sum(0) - 1).abs().max() < 1e-5
+    assert set(np.unique(outs[0][0])) <= set(range(k + 1))
+    assert all((outs[0][0][1:] == o).mean() > 0.01 for o in range(1, k + 1))

@@ -50,6 +50,7 @@ def main():
     splitk = int(sys.argv[sys.argv.index("--splitk") + 1]) if "--splitk" in sys.argv else 0
     only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
     iters = int(sys.argv[sys.argv.index("--iters") + 1]) if "--iters" in sys.argv else 20
+    batch = int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else 0
     lib = _lib.lib()
     torch.cuda.init()
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -60,6 +61,8 @@ def main():
     for name, B, H, W, Cin, Cout, K, st, cnt in SHAPES:
         if only and only not in name:
             continue
+        if batch:
+            B = batch
         ms, fl = C.c_float(), C.c_double()
         _lib.check(lib.stcn_bench_conv(s, B, H, W, Cin, Cout, K, K, st, K // 2, splitk, iters, C.byref(ms), C.byref(fl)))
         if sweep:
