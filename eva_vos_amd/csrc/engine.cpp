@@ -678,7 +678,7 @@ static int do_pass(stcn_engine *e, int idx, bool forward) {
             {
                 Scope sc(&e->prof, STCN_K_OTHER, e->stream, 2.0 * d.hw16 * d.hw16 * 64);
                 attention_read_launch(e->bank_k + (size_t)cs * d.hw16 * 64, e->bank_msq + (size_t)cs * d.hw16, kf.k16, e->pos,
-                                      e->neg, k + 1, d.h16, d.w16, w.pooled, w.amap, w.attn, e->stream);
+                                      e->neg, k + 1, d.h16, d.w16, w.pooled, w.amap, w.attn, AttnScratch{w.gmax, w.tau, w.cand_v}, e->stream);
             }
             for (int o = 1; o <= k; ++o)
                 RC(fusion_logit(*e->model, w, e->stream, e->images4 + (size_t)ti * d.npix * 4, dst + (size_t)o * prs,

@@ -177,10 +177,13 @@ int stcn_test_attention(void *stream, const float *mk, const float *qk, const fl
     if (!mk || !qk || !pos || !neg || !attn || kk < 1 || kk > 9) { set_error("stcn_test_attention: bad arguments"); return STCN_E_INVALID; }
     hipStream_t s = (hipStream_t)stream;
     const int h = nh / 16, w = nw / 16;
-    DevBuf msq, pooled, amap;
+    DevBuf msq, pooled, amap, gm, cm, part;
+    RC(gm.alloc((size_t)256 * h * w)); RC(cm.alloc(h * w)); RC(part.alloc((size_t)16 * h * w * 19));
     RC(msq.alloc(h * w + 64)); RC(pooled.alloc((size_t)kk * 2 * h * w)); RC(amap.alloc((size_t)kk * 2 * h * w));
     rowsumsq_launch(mk, h * w, 64, msq.p, s);
-    attention_read_launch(mk, msq.p, qk, pos, neg, kk, h, w, pooled.p, amap.p, attn, s);
+    HIPCHK(hipMemsetAsync(msq.p, 0, (size_t)(h * w + 64) * 4, s));
+    rowsumsq_launch(mk, h * w, 64, msq.p, s);
+    attention_read_launch(mk, msq.p, qk, pos, neg, kk, h, w, pooled.p, amap.p, attn, AttnScratch{gm.p, cm.p, part.p}, s);
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());
     return STCN_OK;

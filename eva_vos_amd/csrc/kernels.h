@@ -85,9 +85,10 @@ void memory_read_launch(const float *mk, const float *msq, const float *qk, int 
                         const float *mv, long mv_os, int k, float *readout, long ro_os,
                         int32_t *topk_idx, float *topk_w, MemReadScratch scr, hipStream_t s);
 // fusion attention read: mk,qk [hw,64]; pos,neg [kk][16h*16w planes] -> attn [kk][2][nh*nw]
+struct AttnScratch { float *gmax, *cmax, *part; };   // [256][hw], [hw], [16][hw][19]
 void attention_read_launch(const float *mk, const float *msq, const float *qk, const float *pos,
                            const float *neg, int kk, int h, int w, float *pooled, float *amap,
-                           float *attn, hipStream_t s);
+                           float *attn, AttnScratch scr, hipStream_t s);
 // fusion input [nh*nw,12] = (rgb, prev, curr, attn_pos, attn_neg, nc, nr, 0,0,0)
 void pack_fusion_input_launch(const float *img4, const float *prev, const float *curr,
                               const float *attn2, float nc, float nr, long npix, float *out,

@@ -252,22 +252,6 @@ __global__ __launch_bounds__(256) void threshold_kernel(const float *__restrict_
     if (lane == 0) tau[q] = prefix == 0u ? -__builtin_inff() : key2f(prefix - 1u);
 }
 
-// full 128-row tile into a slab Sw[q][row] with stride SLD (used by the attention read)
-__device__ __forceinline__ void s_tile_16q(const float *__restrict__ mk, const float *__restrict__ msq, int N,
-                                           int row0, const f32x4 (&bq)[4], float *Sw, int lane) {
-    const int g = lane >> 4, col = lane & 15;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        HalfFrag h;
-        load_half(mk, msq, N, row0 + half * HROWS, lane, h);
-        f32x4 acc[4];
-        mfma_half(h, bq, acc);
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb)
-            *reinterpret_cast<f32x4 *>(&Sw[col * SLD + (half * 4 + rb) * 16 + 4 * g]) = acc[rb];
-    }
-}
-
 // one wave per query: merge NC*50 chunk winners, softmax, sparse readout
 __global__ __launch_bounds__(256) void merge_readout_kernel(const float *__restrict__ cand_v,
                                                             const int32_t *__restrict__ cand_i, int NC, int Q,
@@ -417,70 +401,88 @@ __global__ void area_pool16_kernel(const float *__restrict__ pos, const float *_
 }
 
 #define STCN_ATT_MAXCH 18   // (k+1)*2 with k <= 8
-__global__ __launch_bounds__(64) void attention_softmax_kernel(const float *__restrict__ mk,
-                                                               const float *__restrict__ msq,
-                                                               const float *__restrict__ qk, int HW,
-                                                               const float *__restrict__ pooled, int nch,
-                                                               float *__restrict__ amap) {
-    // one wave per 16 query columns; lanes stride over the memory rows of each S tile
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *Sw = smem;
-    const int lane = threadIdx.x;
-    const int q0 = blockIdx.x * 16;
+// cmax[q] = max over the G group maxima of pass 1 = exact column maximum of S
+__global__ void colmax_kernel(const float *__restrict__ gmax, int G, int Q, float *__restrict__ cmax) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= Q) return;
+    float m = -__builtin_inff();
+    for (int g = 0; g < G; ++g) m = fmaxf(m, gmax[(long)g * Q + q]);
+    cmax[q] = m;
+}
+
+// pass 2 of the attention read: per (query block, row chunk) partial sums of e = exp(S - cmax[q]):
+//   part[chunk][q][0] = sum_m e,  part[chunk][q][1 + c] = sum_m e * pooled[c][m]
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void attention_pass_kernel(
+    const float *__restrict__ mk, const float *__restrict__ msq, const float *__restrict__ qk, int N, int Q,
+    int steps_per_chunk, const float *__restrict__ cmax, const float *__restrict__ pooled, int nch,
+    float *__restrict__ part) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q0 = (blockIdx.x * WAVES + wave) * 16;
+    if (q0 >= Q) return;
+    const int chunk = blockIdx.y;
+    const int nsteps = (N + HROWS - 1) / HROWS;
+    const int h0 = chunk * steps_per_chunk;
+    const int h1 = min(nsteps, h0 + steps_per_chunk);
+    const int g = lane >> 4, col = lane & 15;
+    const int qcol = min(q0 + col, Q - 1);
     f32x4 bq[4];
-    load_bq(qk, HW, q0, lane, bq);
-    const int ntiles = (HW + TROWS - 1) / TROWS;
-    // state in LDS: m[16][64], l[16][64], acc[16][nch][64]  (lane-private columns)
-    float *Sm = smem + 16 * SLD;
-    float *Sl = Sm + 16 * 64;
-    float *Sa = Sl + 16 * 64;
-    for (int j = 0; j < 16; ++j) {
-        Sm[j * 64 + lane] = -__builtin_inff();
-        Sl[j * 64 + lane] = 0.f;
-        for (int c = 0; c < nch; ++c) Sa[(j * nch + c) * 64 + lane] = 0.f;
-    }
-    for (int tile = 0; tile < ntiles; ++tile) {
-        const int row0 = tile * TROWS;
-        lds_fence();
-        s_tile_16q(mk, msq, HW, row0, bq, Sw, lane);
-        lds_fence();
-        for (int step = 0; step < 2; ++step) {
-            const int row = row0 + step * 64 + lane;
-            if (row < HW) {
-                float pv[STCN_ATT_MAXCH];
+    load_bq(qk, Q, q0, lane, bq);
+    const float cm = cmax[qcol];
+    float l = 0.f, a[STCN_ATT_MAXCH];
 #pragma unroll
-                for (int c = 0; c < STCN_ATT_MAXCH; ++c) pv[c] = c < nch ? pooled[(long)c * HW + row] : 0.f;
-                for (int j = 0; j < 16; ++j) {
-                    const float sv = Sw[j * SLD + step * 64 + lane];
-                    const float mo = Sm[j * 64 + lane];
-                    const float mn = fmaxf(mo, sv);
-                    const float sc = expf(mo - mn);          // exp(-inf) = 0 on the first visit
-                    const float e = expf(sv - mn);
-                    Sm[j * 64 + lane] = mn;
-                    Sl[j * 64 + lane] = Sl[j * 64 + lane] * sc + e;
+    for (int c = 0; c < STCN_ATT_MAXCH; ++c) a[c] = 0.f;
+    for (int h = h0; h < h1; ++h) {
+        const int row0 = h * HROWS;
+        HalfFrag hf;
+        load_half(mk, msq, N, row0, lane, hf);
+        f32x4 acc[4];
+        mfma_half(hf, bq, acc);
 #pragma unroll
-                    for (int c = 0; c < STCN_ATT_MAXCH; ++c)
-                        if (c < nch) {
-                            float *ap = &Sa[(j * nch + c) * 64 + lane];
-                            *ap = *ap * sc + e * pv[c];
-                        }
-                }
+        for (int rb = 0; rb < 4; ++rb) {
+            const int r = row0 + rb * 16 + 4 * g;
+            f32x4 e;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                e[j] = r + j < N ? expf(acc[rb][j] - cm) : 0.f;
+                l += e[j];
             }
+#pragma unroll
+            for (int c = 0; c < STCN_ATT_MAXCH; ++c)
+                if (c < nch) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int rr = r + j < N ? r + j : N - 1;
+                        a[c] += e[j] * pooled[(long)c * N + rr];
+                    }
+                }
         }
     }
-    lds_fence();
-    for (int j = 0; j < 16; ++j) {
-        const float ml = Sm[j * 64 + lane];
-        float M = ml;
-        for (int o = 32; o > 0; o >>= 1) M = fmaxf(M, __shfl_xor(M, o));
-        const float sc = expf(ml - M);                       // lanes that saw no row: exp(-inf) = 0
-        float l = Sl[j * 64 + lane] * sc;
-        for (int o = 32; o > 0; o >>= 1) l += __shfl_xor(l, o);
-        for (int c = 0; c < nch; ++c) {
-            float a = Sa[(j * nch + c) * 64 + lane] * sc;
-            for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
-            if (lane == 0 && q0 + j < HW) amap[(long)c * HW + q0 + j] = a / l;
-        }
+    // sum the 4 lane groups that share a query column (fixed order -> deterministic)
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+#pragma unroll
+    for (int c = 0; c < STCN_ATT_MAXCH; ++c)
+        if (c < nch) { a[c] += __shfl_xor(a[c], 16); a[c] += __shfl_xor(a[c], 32); }
+    if (g == 0 && q0 + col < Q) {
+        float *dst = part + ((long)chunk * Q + q0 + col) * (1 + STCN_ATT_MAXCH);
+        dst[0] = l;
+#pragma unroll
+        for (int c = 0; c < STCN_ATT_MAXCH; ++c)
+            if (c < nch) dst[1 + c] = a[c];
+    }
+}
+
+__global__ void attention_finalize_kernel(const float *__restrict__ part, int NC, int Q, int nch,
+                                          float *__restrict__ amap) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= Q) return;
+    float l = 0.f;
+    for (int ch = 0; ch < NC; ++ch) l += part[((long)ch * Q + q) * (1 + STCN_ATT_MAXCH)];
+    for (int c = 0; c < nch; ++c) {
+        float acc = 0.f;
+        for (int ch = 0; ch < NC; ++ch) acc += part[((long)ch * Q + q) * (1 + STCN_ATT_MAXCH) + 1 + c];
+        amap[(long)c * Q + q] = acc / l;
     }
 }
 
@@ -505,14 +507,26 @@ __global__ void bilinear_up16_kernel(const float *__restrict__ amap, int nch, in
 }
 
 void attention_read_launch(const float *mk, const float *msq, const float *qk, const float *pos, const float *neg,
-                           int kk, int h, int w, float *pooled, float *amap, float *attn, hipStream_t s) {
+                           int kk, int h, int w, float *pooled, float *amap, float *attn, AttnScratch scr,
+                           hipStream_t s) {
     const int hw = h * w, nch = kk * 2;
     hipLaunchKernelGGL(area_pool16_kernel, dim3((unsigned)(((long)nch * hw + 255) / 256)), dim3(256), 0, s, pos, neg,
                        kk, h, w, pooled);
-    const size_t lds = (size_t)(16 * SLD + 2 * 16 * 64 + 16 * nch * 64) * sizeof(float);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&attention_softmax_kernel),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(attention_softmax_kernel, dim3((hw + 15) / 16), dim3(64), lds, s, mk, msq, qk, hw, pooled, nch,
+    constexpr int WAVES = 4;
+    const int steps = (hw + HROWS - 1) / HROWS;
+    const int qblocks = (hw + 16 * WAVES - 1) / (16 * WAVES);
+    int NC = (512 + qblocks - 1) / qblocks;
+    if (NC > MAXCHUNK) NC = MAXCHUNK;
+    if (NC > steps) NC = steps;
+    const int spc = (steps + NC - 1) / NC;
+    const int NCeff = (steps + spc - 1) / spc;
+    const dim3 grid(qblocks, NCeff);
+    hipLaunchKernelGGL((affinity_pass_kernel<WAVES, false>), grid, dim3(64 * WAVES), 0, s, mk, msq, qk, hw, hw, spc,
+                       scr.gmax, (const float *)nullptr, (float *)nullptr, (int32_t *)nullptr);
+    hipLaunchKernelGGL(colmax_kernel, dim3((hw + 255) / 256), dim3(256), 0, s, scr.gmax, NCeff * NGRP, hw, scr.cmax);
+    hipLaunchKernelGGL((attention_pass_kernel<WAVES>), grid, dim3(64 * WAVES), 0, s, mk, msq, qk, hw, hw, spc, scr.cmax,
+                       pooled, nch, scr.part);
+    hipLaunchKernelGGL(attention_finalize_kernel, dim3((hw + 255) / 256), dim3(256), 0, s, scr.part, NCeff, hw, nch,
                        amap);
     const long tot = (long)nch * 256 * hw;
     hipLaunchKernelGGL(bilinear_up16_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, amap, nch, h, w,
