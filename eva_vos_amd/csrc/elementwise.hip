@@ -308,12 +308,15 @@ void pack_fusion_input_launch(const float *img4, const float *prev, const float 
 // CBAM (cbam.py:21-77): channel gate (avg+max pool -> shared MLP -> sigmoid), then spatial gate
 // (channel max/mean -> 7x7 conv -> sigmoid); FeatureFusionBlock adds the result to x (modules.py:48-50).
 // scratch layout per call: pooled [B][2][512] | gate [B][512] | sp [B][hw][2] | (unused)
-__global__ __launch_bounds__(256) void cbam_pool_kernel(const float *__restrict__ x, int hw, float *__restrict__ pooled) {
-    // grid (8 channel groups of 64, B); 4 row slices per block
-    const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+#define CBAM_SLICES 16
+// partial avg/max pooling: grid (8 channel groups of 64, B, CBAM_SLICES row slices); part [B][SLICES][2][512]
+__global__ __launch_bounds__(256) void cbam_pool_kernel(const float *__restrict__ x, int hw, float *__restrict__ part) {
+    const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6, z = blockIdx.z;
+    const int per = (hw + CBAM_SLICES - 1) / CBAM_SLICES;
+    const int p0 = z * per, p1 = min(hw, p0 + per);
     const float *xb = x + (long)b * hw * 512 + c;
     float sum = 0.f, mx = -__builtin_inff();
-    for (int p = sl; p < hw; p += 4) {
+    for (int p = p0 + sl; p < p1; p += 4) {
         const float v = xb[(long)p * 512];
         sum += v;
         mx = fmaxf(mx, v);
@@ -326,19 +329,32 @@ __global__ __launch_bounds__(256) void cbam_pool_kernel(const float *__restrict_
         const int l = threadIdx.x;
         sum = ssum[l] + ssum[l + 64] + ssum[l + 128] + ssum[l + 192];
         mx = fmaxf(fmaxf(smax[l], smax[l + 64]), fmaxf(smax[l + 128], smax[l + 192]));
-        pooled[(long)b * 1024 + c] = sum / (float)hw;
-        pooled[(long)b * 1024 + 512 + c] = mx;
+        float *dst = part + ((long)b * CBAM_SLICES + z) * 1024;
+        dst[c] = sum;
+        dst[512 + c] = mx;
     }
 }
 
-__global__ __launch_bounds__(512) void cbam_mlp_kernel(const float *__restrict__ pooled, CbamW cw,
+__global__ __launch_bounds__(512) void cbam_mlp_kernel(const float *__restrict__ part, int hw, CbamW cw,
                                                        float *__restrict__ gate) {
     const int b = blockIdx.x, t = threadIdx.x;
     __shared__ float hid[64];
+    __shared__ float pooled[1024];            // [avg 512 | max 512]
+    {
+        float sum = 0.f, mx = -__builtin_inff();
+        for (int z = 0; z < CBAM_SLICES; ++z) {          // fixed order: deterministic
+            const float *src = part + ((long)b * CBAM_SLICES + z) * 1024;
+            sum += src[t];
+            mx = fmaxf(mx, src[512 + t]);
+        }
+        pooled[t] = sum / (float)hw;
+        pooled[512 + t] = mx;
+    }
+    __syncthreads();
     // 64 hidden units (2 inputs x 32); 8 lanes cooperate on one 512-long dot product
     const int unit = t >> 3, sub = t & 7;
     const int which = unit >> 5, h = unit & 31;
-    const float *v = pooled + (long)b * 1024 + which * 512;
+    const float *v = pooled + which * 512;
     float acc = 0.f;
     for (int c = sub; c < 512; c += 8) acc += cw.w1[h * 512 + c] * v[c];
     for (int o = 4; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
@@ -407,9 +423,9 @@ __global__ __launch_bounds__(256) void cbam_apply_kernel(const float *__restrict
 
 void cbam_launch(const float *x, float *out, int B, int h, int w, const CbamW &cw, float *scratch, hipStream_t s) {
     const int hw = h * w;
-    float *pooled = scratch, *gate = scratch + (long)B * 1024, *sp = gate + (long)B * 512;
-    hipLaunchKernelGGL(cbam_pool_kernel, dim3(8, B), dim3(256), 0, s, x, hw, pooled);
-    hipLaunchKernelGGL(cbam_mlp_kernel, dim3(B), dim3(512), 0, s, pooled, cw, gate);
+    float *part = scratch, *gate = scratch + (long)B * CBAM_SLICES * 1024, *sp = gate + (long)B * 512;
+    hipLaunchKernelGGL(cbam_pool_kernel, dim3(8, B, CBAM_SLICES), dim3(256), 0, s, x, hw, part);
+    hipLaunchKernelGGL(cbam_mlp_kernel, dim3(B), dim3(512), 0, s, part, hw, cw, gate);
     const long total = (long)B * hw;
     hipLaunchKernelGGL(cbam_spool_kernel, dim3(nblocks(total * 64)), dim3(256), 0, s, x, gate, hw, total, sp);
     hipLaunchKernelGGL(cbam_apply_kernel, dim3(nblocks(total * 64)), dim3(256), 0, s, x, gate, sp, cw, h, w, total,

@@ -213,7 +213,7 @@ int Work::init(int nh, int nw, int k_) {
         if ((rc = alloc((void **)b, S * sizeof(float)))) return rc;
     splitk_floats = (size_t)32 * 1024 * 1024;      // 128 MB of fp32 slabs; conv falls back to fewer splits
     if ((rc = alloc((void **)&splitk, splitk_floats * sizeof(float)))) return rc;
-    if ((rc = alloc((void **)&cbam, (size_t)k * (1024 + 512 + 3 * d.hw16) * sizeof(float)))) return rc;
+    if ((rc = alloc((void **)&cbam, (size_t)k * (16 * 1024 + 512 + 3 * d.hw16) * sizeof(float)))) return rc;
     if ((rc = alloc((void **)&readout, (size_t)k * d.hw16 * 512 * sizeof(float)))) return rc;
     if ((rc = alloc((void **)&logit4, (size_t)k * d.hw4 * sizeof(float)))) return rc;
     if ((rc = alloc((void **)&flogit, (size_t)k * d.npix * sizeof(float)))) return rc;

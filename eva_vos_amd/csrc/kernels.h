@@ -72,7 +72,7 @@ void interact_mask_launch(const float *mask, int mc, int H, int W, int nh, int n
 
 // ---------------------------------------------------------------- CBAM (cbam.py:21-77)
 struct CbamW { const float *w1, *b1, *w2, *b2, *wsp; float bsp; };  // 512->32->512 MLP, 7x7 [2] conv
-// x [B,hw,512] -> out = x + CBAM(x); scratch >= B*(1024 + 512 + 3*hw) floats
+// x [B,hw,512] -> out = x + CBAM(x); scratch >= B*(16*1024 + 512 + 2*hw) floats
 void cbam_launch(const float *x, float *out, int B, int h, int w, const CbamW &cw, float *scratch,
                  hipStream_t s);
 
