@@ -134,6 +134,32 @@ static int add_convs(Model &m, const std::map<std::string, HostT> &sd) {
         if (rc) return rc;
         cw.bias0 = bias[0];
         m.conv[pre] = cw;
+        // Convs over a channel concat [per-object part | frame-only part]: conv is linear in the input
+        // channels, so the frame-only half (with the bias) is computed once per frame and cached:
+        //   "<name>#a" = channels [0,c0) without bias, "<name>#b" = channels [c0,cin) with the bias.
+        static const struct { const char *name; int c0; } splits[] = {
+            {"decoder.compress.conv1", 512}, {"decoder.compress.downsample", 512},
+            {"value_encoder.fuser.block1.conv1", 256}, {"value_encoder.fuser.block1.downsample", 256}};
+        for (const auto &sp : splits) {
+            if (pre != sp.name) continue;
+            for (int part = 0; part < 2; ++part) {
+                const int lo = part ? sp.c0 : 0, hi = part ? cin : sp.c0;
+                ConvW pw;
+                pw.cout = cout; pw.cin = hi - lo; pw.cin_p = hi - lo; pw.kh = kh; pw.kw = kw;
+                pw.K = kh * kw * pw.cin_p; pw.Kp = (pw.K + 31) / 32 * 32;
+                std::vector<float> ww((size_t)cout * pw.Kp, 0.f);
+                for (int n = 0; n < cout; ++n)
+                    for (int c = lo; c < hi; ++c)
+                        for (int y = 0; y < kh; ++y)
+                            for (int x = 0; x < kw; ++x)
+                                ww[(size_t)n * pw.Kp + (size_t)(y * kw + x) * pw.cin_p + (c - lo)] =
+                                    wt.p[(((size_t)n * cin + c) * kh + y) * kw + x] * scale[n];
+                std::vector<float> bb = part ? bias : std::vector<float>(cout, 0.f);
+                if ((rc = upload(m, ww, &pw.w)) || (rc = upload(m, bb, &pw.bias))) return rc;
+                pw.bias0 = bb[0];
+                m.conv[pre + (part ? "#b" : "#a")] = pw;
+            }
+        }
     }
     return STCN_OK;
 }
@@ -318,6 +344,29 @@ int encode_key(const Model &m, Work &w, hipStream_t s, const float *img4, const 
         if (o.msq) { Scope sc(w.prof, STCN_K_ELEMWISE, s); rowsumsq_launch(o.k16, d.hw16, 64, o.msq, s); }
     }
     if (o.f16_thin) RC(conv1(m, w, s, "key_comp", o.f16, 1024, 1, d.h16, d.w16, 1, o.f16_thin, nullptr, 0, 0));
+    if (o.f16_thin && o.dthin) {   // frame-only halves of decoder.compress (see add_convs)
+        RC(conv1(m, w, s, "decoder.compress.downsample#b", o.f16_thin, 512, 1, d.h16, d.w16, 1, o.dthin, nullptr, 0, 0));
+        RC(conv1(m, w, s, "decoder.compress.conv1#b", o.f16_thin, 512, 1, d.h16, d.w16, 1, o.cthin, nullptr, 1, 0));
+    }
+    return STCN_OK;
+}
+
+// frame-only halves of value_encoder.fuser.block1 over f16 (computed lazily, on the first value encode of a frame)
+int value_frame_parts(const Model &m, Work &w, hipStream_t s, const float *f16, float *vd, float *vc) {
+    const Dims &d = w.d;
+    RC(conv1(m, w, s, "value_encoder.fuser.block1.downsample#b", f16, 1024, 1, d.h16, d.w16, 1, vd, nullptr, 0, 0));
+    RC(conv1(m, w, s, "value_encoder.fuser.block1.conv1#b", f16, 1024, 1, d.h16, d.w16, 1, vc, nullptr, 1, 0));
+    return STCN_OK;
+}
+
+// ResBlock(cat[x, frame part]) with the frame part's conv1 / downsample contributions precomputed (dpart, cpart)
+static int resblock_split(const Model &m, Work &w, hipStream_t s, const std::string &p, const float *x, int c, int B,
+                          int H, int W, const float *dpart, const float *cpart, float *t1, float *t2, float *out, long out_bs) {
+    const ConvW &cw = m.c(p + ".conv1");
+    const long obs = (long)H * W * cw.cout, xbs = (long)H * W * c;
+    RC(run_conv(m, w, s, (p + ".downsample#a").c_str(), x, c, xbs, nullptr, 0, 0, B, H, W, 1, t2, 0, dpart, 0, 0, 0));
+    RC(run_conv(m, w, s, (p + ".conv1#a").c_str(), x, c, xbs, nullptr, 0, 0, B, H, W, 1, t1, 0, cpart, 0, 1, 1));
+    RC(run_conv(m, w, s, (p + ".conv2").c_str(), t1, cw.cout, obs, nullptr, 0, 0, B, H, W, 1, out, out_bs, t2, obs, 0, 0));
     return STCN_OK;
 }
 
@@ -341,7 +390,7 @@ static int resblock(const Model &m, Work &w, hipStream_t s, const std::string &p
 
 // ValueEncoder (modules.py:93-124, mod_resnet.py:49-78) + FeatureFusionBlock (modules.py:38-52)
 int encode_value(const Model &m, Work &w, hipStream_t s, const float *img4, const float *f16, const float *masks,
-                 long mask_stride, float *out, long out_bs) {
+                 long mask_stride, float *out, long out_bs, const float *vd, const float *vc) {
     const Dims &d = w.d;
     const int k = w.k;
     { Scope sc(w.prof, STCN_K_ELEMWISE, s); pack_value_input_launch(img4, masks, mask_stride, k, (int)d.npix, w.vin, s); }
@@ -365,7 +414,10 @@ int encode_value(const Model &m, Work &w, hipStream_t s, const float *img4, cons
         }
     // fuser: block1(cat[x256, f16]) -> x + CBAM(x) -> block2
     const std::string f = "value_encoder.fuser.";
-    RC(resblock(m, w, s, f + "block1", w.B, 256, (long)d.hw16 * 256, f16, 1024, 0, k, d.h16, d.w16, w.C, w.D, w.A, 0));
+    if (vd && vc)
+        RC(resblock_split(m, w, s, f + "block1", w.B, 256, k, d.h16, d.w16, vd, vc, w.C, w.D, w.A, 0));
+    else
+        RC(resblock(m, w, s, f + "block1", w.B, 256, (long)d.hw16 * 256, f16, 1024, 0, k, d.h16, d.w16, w.C, w.D, w.A, 0));
     { Scope sc(w.prof, STCN_K_OTHER, s); cbam_launch(w.A, w.C, k, d.h16, d.w16, m.cbam, w.cbam, s); }
     RC(resblock(m, w, s, f + "block2", w.C, 512, (long)d.hw16 * 512, nullptr, 0, 0, k, d.h16, d.w16, w.D, w.A, out, out_bs));
     return STCN_OK;
@@ -373,11 +425,14 @@ int encode_value(const Model &m, Work &w, hipStream_t s, const float *img4, cons
 
 // Decoder (prop_net.py:13-30) on cat[readout, f16_thin] + sigmoid + aggregate_wbg
 int decode(const Model &m, Work &w, hipStream_t s, const float *readout, const float *f16_thin, const float *s8,
-           const float *s4, float *agg, long agg_stride) {
+           const float *s4, float *agg, long agg_stride, const float *dthin, const float *cthin) {
     const Dims &d = w.d;
     const int k = w.k;
-    RC(resblock(m, w, s, "decoder.compress", readout, 512, (long)d.hw16 * 512, f16_thin, 512, 0, k, d.h16, d.w16, w.C,
-                w.D, w.A, 0));
+    if (dthin && cthin)
+        RC(resblock_split(m, w, s, "decoder.compress", readout, 512, k, d.h16, d.w16, dthin, cthin, w.C, w.D, w.A, 0));
+    else
+        RC(resblock(m, w, s, "decoder.compress", readout, 512, (long)d.hw16 * 512, f16_thin, 512, 0, k, d.h16, d.w16, w.C,
+                    w.D, w.A, 0));
     { Scope sc(w.prof, STCN_K_ELEMWISE, s); upsample2x_add_launch(w.A, s8, w.B, k, d.h16, d.w16, 512, s); }
     RC(resblock(m, w, s, "decoder.up_16_8.out_conv", w.B, 512, (long)d.hw8 * 512, nullptr, 0, 0, k, d.h8, d.w8, w.C, w.D,
                 w.A, 0));
@@ -446,7 +501,7 @@ static int eng_alloc(stcn_engine *e, void **p, size_t bytes) {
     return STCN_OK;
 }
 
-struct SlotPtrs { float *k16, *msq, *f16_thin, *f16, *s8, *s4; };
+struct SlotPtrs { float *k16, *msq, *f16_thin, *f16, *s8, *s4, *dthin, *cthin, *vd, *vc; };
 static SlotPtrs slot_ptrs(const stcn_engine *e, int slot) {
     const Dims &d = e->d;
     float *b = e->cache + (size_t)slot * e->slot_floats;
@@ -456,7 +511,11 @@ static SlotPtrs slot_ptrs(const stcn_engine *e, int slot) {
     p.f16_thin = b; b += (size_t)d.hw16 * 512;
     p.f16 = b; b += (size_t)d.hw16 * 1024;
     p.s8 = b; b += (size_t)d.hw8 * 512;
-    p.s4 = b;
+    p.s4 = b; b += (size_t)d.hw4 * 256;
+    p.dthin = b; b += (size_t)d.hw16 * 512;
+    p.cthin = b; b += (size_t)d.hw16 * 512;
+    p.vd = b; b += (size_t)d.hw16 * 512;
+    p.vc = b;
     return p;
 }
 
@@ -488,9 +547,11 @@ static int engine_alloc_common(stcn_engine *e) {
     const Dims &d = e->d;
     RC(eng_alloc(e, (void **)&e->images4, (size_t)e->T * d.npix * 4 * 4));
     e->n_slots = e->T < 106 ? e->T : 106;                 // key_buf holds at most 106 frames (inference_core.py:46,118)
-    e->slot_floats = (size_t)d.hw16 * (64 + 512 + 1024) + (size_t)(d.hw16 + 3) / 4 * 4 + (size_t)d.hw8 * 512 + (size_t)d.hw4 * 256;
+    e->slot_floats = (size_t)d.hw16 * (64 + 512 + 1024) + (size_t)(d.hw16 + 3) / 4 * 4 + (size_t)d.hw8 * 512 + (size_t)d.hw4 * 256 +
+                     (size_t)4 * d.hw16 * 512;
     RC(eng_alloc(e, (void **)&e->cache, (size_t)e->n_slots * e->slot_floats * 4));
     e->slot_of.assign(e->T, -1);
+    e->vparts_ready.assign(e->T, 0);
     RC(eng_alloc(e, (void **)&e->mask_pad, (size_t)(e->k + 1) * d.npix * 4));
     RC(eng_alloc(e, (void **)&e->pos, (size_t)(e->k + 1) * d.npix * 4));
     RC(eng_alloc(e, (void **)&e->neg, (size_t)(e->k + 1) * d.npix * 4));
@@ -572,7 +633,7 @@ int stcn_engine_clone(const stcn_engine *src, float *prob_dev, uint8_t *masks_de
     if (src->side) HIPCHK(hipStreamSynchronize(src->side));
     HIPCHK(hipMemcpyAsync(e->images4, src->images4, (size_t)e->T * d.npix * 16, hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(e->cache, src->cache, (size_t)e->n_slots * e->slot_floats * 4, hipMemcpyDeviceToDevice, e->stream));
-    e->slot_of = src->slot_of; e->n_cached = src->n_cached;
+    e->slot_of = src->slot_of; e->n_cached = src->n_cached; e->vparts_ready = src->vparts_ready;
     e->n_certain = src->n_certain; e->interacted = src->interacted;
     const size_t crow = (size_t)e->n_certain * d.hw16;
     if (crow) {
@@ -597,12 +658,14 @@ static int enqueue_key(stcn_engine *e, int ti) {
     if (e->slot_of[ti] >= 0) return STCN_OK;
     if (e->n_cached >= e->n_slots) {                         // flush-all policy of the reference
         std::fill(e->slot_of.begin(), e->slot_of.end(), -1);
+        std::fill(e->vparts_ready.begin(), e->vparts_ready.end(), 0);
         e->n_cached = 0;
     }
     const int slot = e->n_cached++;
     e->slot_of[ti] = slot;
+    e->vparts_ready[ti] = 0;
     const SlotPtrs p = slot_ptrs(e, slot);
-    KeyOut ko{p.k16, p.msq, p.f16_thin, p.f16, p.s8, p.s4, nullptr, nullptr};
+    KeyOut ko{p.k16, p.msq, p.f16_thin, p.f16, p.s8, p.s4, nullptr, nullptr, p.dthin, p.cthin};
     const float *img = e->images4 + (size_t)ti * e->d.npix * 4;
     if (e->lookahead > 0) {
         RC(encode_key(*e->model, e->work_side, e->side, img, ko));
@@ -632,8 +695,12 @@ static int bank_insert(stcn_engine *e, int slot, int ti, const SlotPtrs &kf, con
     const Dims &d = e->d;
     HIPCHK(hipMemcpyAsync(e->bank_k + (size_t)slot * d.hw16 * 64, kf.k16, (size_t)d.hw16 * 64 * 4, hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(e->bank_msq + (size_t)slot * d.hw16, kf.msq, (size_t)d.hw16 * 4, hipMemcpyDeviceToDevice, e->stream));
+    if (!e->vparts_ready[ti]) {
+        RC(value_frame_parts(*e->model, e->work, e->stream, kf.f16, kf.vd, kf.vc));
+        e->vparts_ready[ti] = 1;
+    }
     RC(encode_value(*e->model, e->work, e->stream, e->images4 + (size_t)ti * d.npix * 4, kf.f16, masks, mask_stride,
-                    bank_v_slot(e, slot), (long)e->bank_cap * d.hw16 * 512));
+                    bank_v_slot(e, slot), (long)e->bank_cap * d.hw16 * 512, kf.vd, kf.vc));
     e->stats.value_enc++;
     return STCN_OK;
 }
@@ -663,7 +730,7 @@ static int do_pass(stcn_engine *e, int idx, bool forward) {
             memory_read_launch(e->bank_k, e->bank_msq, kf.k16, N, d.hw16, e->bank_v, (long)e->bank_cap * d.hw16 * 512, k,
                                w.readout, (long)d.hw16 * 512, nullptr, nullptr, MemReadScratch{w.cand_v, w.cand_i, w.gmax, w.tau}, e->stream);
         }
-        RC(decode(*e->model, w, e->stream, w.readout, kf.f16_thin, kf.s8, kf.s4, w.agg, d.npix));
+        RC(decode(*e->model, w, e->stream, w.readout, kf.f16_thin, kf.s8, kf.s4, w.agg, d.npix, kf.dthin, kf.cthin));
         if (ti != end && std::abs(ti - last_ti) >= e->mem_freq) {
             RC(bank_insert(e, m_front, ti, kf, w.agg + d.npix, d.npix));
             ++m_front;

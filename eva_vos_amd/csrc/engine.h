@@ -90,15 +90,20 @@ struct Work {
 };
 
 // ---- stages (enqueue only) -----------------------------------------------------------------
-struct KeyOut { float *k16, *msq, *f16_thin, *f16, *s8, *s4, *f8_copy, *f4_copy; };
+struct KeyOut { float *k16, *msq, *f16_thin, *f16, *s8, *s4, *f8_copy, *f4_copy, *dthin = nullptr, *cthin = nullptr; };
 int run_conv(const Model &m, Work &w, hipStream_t s, const char *name, const float *x0, int c0, long bs0,
              const float *x1, int c1, long bs1, int B, int H, int W, int stride, float *y, long y_bs,
              const float *res, long res_bs, int relu_in, int relu_out, int force_splitk = 0);
 int encode_key(const Model &m, Work &w, hipStream_t s, const float *img4, const KeyOut &o);
+// vd / vc: cached frame-only halves of fuser.block1 (nullptr: compute the full two-source convs)
 int encode_value(const Model &m, Work &w, hipStream_t s, const float *img4, const float *f16,
-                 const float *masks, long mask_stride, float *out, long out_bs);
+                 const float *masks, long mask_stride, float *out, long out_bs, const float *vd = nullptr,
+                 const float *vc = nullptr);
+int value_frame_parts(const Model &m, Work &w, hipStream_t s, const float *f16, float *vd, float *vc);
+// dthin / cthin: cached frame-only halves of decoder.compress (nullptr: full two-source convs)
 int decode(const Model &m, Work &w, hipStream_t s, const float *readout, const float *f16_thin,
-           const float *s8, const float *s4, float *agg, long agg_stride);
+           const float *s8, const float *s4, float *agg, long agg_stride, const float *dthin = nullptr,
+           const float *cthin = nullptr);
 int fusion_logit(const Model &m, Work &w, hipStream_t s, const float *img4, const float *prev,
                  const float *curr, const float *attn2, float nc, float nr, float *logit);
 
@@ -118,6 +123,7 @@ struct stcn_engine {
     // key-feature cache
     int n_slots = 0;
     std::vector<int> slot_of;          // frame -> slot or -1
+    std::vector<char> vparts_ready;    // frame -> value-encoder frame parts (vd, vc) are in its slot
     int n_cached = 0;
     float *cache = nullptr; size_t slot_floats = 0;
     // memory bank: rows = slots * hw16

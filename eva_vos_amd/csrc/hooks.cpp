@@ -116,7 +116,7 @@ int stcn_test_encode_key(const stcn_model *m, void *stream, const float *img, in
     RC(img4.alloc((size_t)d.npix * 4)); RC(tf16.alloc((size_t)d.hw16 * 1024)); RC(tk16.alloc((size_t)d.hw16 * 64));
     RC(tmsq.alloc(d.hw16));
     RC(pack_one(img, nh, nw, img4.p, s));
-    KeyOut ko{k16 ? k16 : tk16.p, tmsq.p, f16_thin, f16 ? f16 : tf16.p, nullptr, nullptr, f8, f4};
+    KeyOut ko{k16 ? k16 : tk16.p, tmsq.p, f16_thin, f16 ? f16 : tf16.p, nullptr, nullptr, f8, f4, nullptr, nullptr};
     RC(encode_key(m->m, t.w, s, img4.p, ko));
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());
