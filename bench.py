@@ -175,6 +175,8 @@ def main():
     dt = time.perf_counter() - t0
     frames = sum(r[0] for r in res)
     last = res[0][1]
+    # every video of this rank has the same input: concurrent lanes must agree bit for bit
+    lanes_identical = all(np.array_equal(r[1], last) for r in res)
 
     # Roofline leg: the same step (fresh engine, interact(mask,0)) on ONE stream with per-launch HIP events on
     # that stream.  Kept apart from the timed region on purpose: (i) two events per launch cost ~13 % of
@@ -243,6 +245,7 @@ def main():
                        "weights": "synthetic recipe seed 0 (no checkpoints offline)"},
             "ms_per_frame": 1e3 * dt_all / (frames_all / world),
             "jf_rows_rank_J_F_JF": rows.round(4).tolist(),
+            "concurrent_videos_bit_identical": bool(lanes_identical),
         }
         if r2 is not None:
             out["r2_frames_per_s_rank0"] = r2

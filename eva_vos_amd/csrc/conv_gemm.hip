@@ -343,9 +343,16 @@ void conv_launch(const ConvP &p, hipStream_t s, hipEvent_t *ev_gemm, hipEvent_t 
     const dim3 grid(ntile * p.splitk);
     const bool smallc = (p.Cin % 32) != 0 || (p.x1 && (p.c0 % 32) != 0) || p.KH * p.KW > 32;
     hipEvent_t e0 = ev_gemm ? ev_gemm[0] : nullptr, e1 = ev_gemm ? ev_gemm[1] : nullptr;
-#define STCN_LAUNCH(WM_, WN_, SC_, RL_)                                                                          \
-    hipExtLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, SC_, RL_>), grid, dim3(256), lds, s, e0, e1, 0, p, tiles_n, \
-                          ntile, per)
+    if (p.mode == 1) {
+        conv_f16x3_launch(p, tiles_n, ntile, per, grid, s, e0, e1);
+    } else {
+#define STCN_LAUNCH(WM_, WN_, SC_, RL_)                                                                              \
+    do {                                                                                                              \
+        if (e0) hipExtLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, SC_, RL_>), grid, dim3(256), lds, s, e0, e1, 0, p,  \
+                                      tiles_n, ntile, per);                                                           \
+        else hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, SC_, RL_>), grid, dim3(256), lds, s, p, tiles_n, ntile,   \
+                                per);                                                                                 \
+    } while (0)
     const int key = (narrow ? 4 : 0) | (smallc ? 2 : 0) | (p.relu_in ? 1 : 0);
     switch (key) {
         case 0: STCN_LAUNCH(2, 2, false, false); break;
@@ -357,13 +364,16 @@ void conv_launch(const ConvP &p, hipStream_t s, hipEvent_t *ev_gemm, hipEvent_t 
         case 6: STCN_LAUNCH(4, 1, true, false); break;
         default: STCN_LAUNCH(4, 1, true, true); break;
     }
+    }
 #undef STCN_LAUNCH
     if (p.splitk > 1) {
         const long total4 = (long)p.M * p.N / 4;
         long blocks = (total4 + 255) / 256;
         if (blocks > 2048) blocks = 2048;
-        hipExtLaunchKernelGGL(conv_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, ev_red ? ev_red[0] : nullptr,
-                              ev_red ? ev_red[1] : nullptr, 0, p);
+        if (ev_red)
+            hipExtLaunchKernelGGL(conv_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, ev_red[0], ev_red[1], 0, p);
+        else
+            hipLaunchKernelGGL(conv_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
     }
 }
 

@@ -1,0 +1,298 @@
+// conv_gemm_f16.hip - implicit-GEMM convolution on the f16 MFMA pipe with fp32-grade accuracy ("f16x3").
+//
+// Same op, layout and pipeline as conv_gemm.hip; only the arithmetic differs.  Every fp32 operand is split
+// into two fp16 numbers, x = hi + lo (hi = fp16(x), lo = fp16(x - hi)), and a product is evaluated as
+//     x*w ~= hi_x*hi_w + hi_x*lo_w + lo_x*hi_w          (the dropped lo_x*lo_w term is <= 2^-22 |x*w|)
+// with three v_mfma_f32_32x32x16_f16 per 16-deep K step accumulating into ONE fp32 accumulator (fp16 x fp16
+// products are exact in fp32).  To keep `lo` a NORMAL fp16 number, operands are pre-scaled by powers of two
+// (exact): activations by 2^2 at staging time, weights per output channel by 2^s_n at model build (|w'| ~
+// 2^10); the epilogue multiplies the accumulator by 2^-(2+s_n).  Error per product ~2^-22, i.e. fp32-grade
+// (tests hold this path to the same tolerances as the fp32 path), at 3/16 of the fp32-MFMA cost: the f16 pipe
+// is 16x faster and, unlike the fp32 MFMA, runs beside the VALU.
+//   * A: global fp32 (buffer loads, OOB -> 0) -> registers -> split -> LDS as fp16 hi / lo tiles
+//   * B: weights pre-split in HBM as fp16 hi / lo arrays [N][Kp] -> LDS
+//   * LDS rows: 32 halfs + 8 pad = 80 B (5 slots, odd) -> conflict-free ds_read_b128 fragments
+//   * 6 MFMAs per K tile of 32 per wave (32x32 accumulator), same 2-register-set software pipeline.
+#include <hip/hip_ext.h>
+
+#include <type_traits>
+
+#include "kernels.h"
+
+namespace stcn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+static constexpr int BK = 32;
+static constexpr int LDH = 40;                    // LDS row stride in halfs (80 B)
+static constexpr unsigned OOB = 0x80000000u;
+static constexpr float ASCALE = 4.f;              // activations are split as fp16(4 x): overflow only beyond |x| = 16376
+
+template <int WM, int WN, bool SMALLC, bool RELU>
+__global__ __launch_bounds__(256) void conv_gemm_f16x3_kernel(const ConvP p, const int tiles_n, const int ntile,
+                                                              const int kt_per_split) {
+    constexpr int BM = 32 * WM, BN = 32 * WN;
+    extern __shared__ __attribute__((aligned(16))) _Float16 smh[];
+    // per buffer: Ah[BM][LDH] Al[BM][LDH] Bh[BN][LDH] Bl[BN][LDH]
+    constexpr int BUF = 2 * (BM + BN) * LDH;
+    _Float16 *const Ah = smh, *const Al = smh + BM * LDH, *const Bh = smh + 2 * BM * LDH,
+                   *const Bl = smh + 2 * BM * LDH + BN * LDH;
+
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int split = swz / ntile;
+    const int tile = swz - split * ntile;
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int kc = t & 7, r0 = t >> 3;            // A staging: row r0 (+32 i), 4-float chunk kc
+    const int bc = t & 3, br = t >> 2;            // B staging: row br (64 rows), 8-half chunk bc
+
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x0), 0, p.x0_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x1 ? p.x1 : p.x0), 0, p.x1 ? p.x1_bytes : p.x0_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rwh = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(p.w_hi), 0, p.w_bytes / 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rwl = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(p.w_lo), 0, p.w_bytes / 2, 0x00020000);
+
+    int ih0[WM], iw0[WM], roff0[WM], roff1[WM];
+    unsigned vmask[WM];
+    bool rvalid[WM];
+    const int ohw = p.OH * p.OW;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+        const int m = tm * BM + r0 + 32 * i;
+        rvalid[i] = m < p.M;
+        const int mm = rvalid[i] ? m : 0;
+        const int b = mm / ohw, pix = mm - b * ohw;
+        const int oh = pix / p.OW, ow = pix - oh * p.OW;
+        ih0[i] = oh * p.stride - p.pad;
+        iw0[i] = ow * p.stride - p.pad;
+        roff0[i] = (b * (int)p.bs0 + (ih0[i] * p.W + iw0[i]) * p.c0 + (SMALLC ? 0 : kc * 4)) * 4;
+        roff1[i] = (b * (int)p.bs1 + (ih0[i] * p.W + iw0[i]) * p.c1 + (SMALLC ? 0 : kc * 4)) * 4;
+        unsigned vm = 0;
+        if (!SMALLC) {
+            int bit = 0;
+            for (int kh = 0; kh < p.KH; ++kh)
+                for (int kw = 0; kw < p.KW; ++kw, ++bit)
+                    if (rvalid[i] && (unsigned)(ih0[i] + kh) < (unsigned)p.H && (unsigned)(iw0[i] + kw) < (unsigned)p.W)
+                        vm |= 1u << bit;
+        }
+        vmask[i] = vm;
+    }
+    // weights: one 16-byte chunk (8 halfs) of hi and of lo per thread per K tile when BN = 64; BN = 32: t < 128
+    const bool bact = br < BN;
+    const int bn = tn * BN + br;
+    const unsigned woff = (bact && bn < p.N) ? (unsigned)((bn * p.Kp + bc * 8) * 2) : OOB;
+
+    const int nkt = p.Kp / BK;
+    const int kt0 = split * kt_per_split;
+    const int kt1 = min(nkt, kt0 + kt_per_split);
+
+    int u_kh, u_kw, u_cb;
+    {
+        const int k0 = kt0 * BK;
+        const int tap = k0 / p.Cin;
+        u_cb = k0 - tap * p.Cin;
+        u_kh = tap / p.KW;
+        u_kw = tap - u_kh * p.KW;
+    }
+
+    f32x4 ra[2][WM];
+    u32x4 rbh[2], rbl[2];
+    int g_kh = 0, g_kw = 0, g_coff = 0;
+    unsigned g_bit = 0;
+    bool g_src1 = false, g_kvalid = true;
+    auto g_tap = [&](int kt) {
+        if (SMALLC) {
+            const int k = kt * BK + kc * 4;
+            g_kvalid = k < p.K;
+            const int tap = k / p.Cin;
+            const int c = k - tap * p.Cin;
+            g_kh = tap / p.KW;
+            g_kw = tap - g_kh * p.KW;
+            g_coff = ((g_kh * p.W + g_kw) * p.c0 + c) * 4;
+        } else {
+            g_src1 = u_cb >= p.c0;
+            g_bit = (unsigned)(u_kh * p.KW + u_kw);
+            const int cs = g_src1 ? p.c1 : p.c0;
+            g_coff = ((u_kh * p.W + u_kw) * cs + (g_src1 ? u_cb - p.c0 : u_cb)) * 4;
+            u_cb += BK;
+            if (u_cb >= p.Cin) { u_cb = 0; if (++u_kw == p.KW) { u_kw = 0; ++u_kh; } }
+        }
+    };
+    auto g_a = [&](int i, auto setc) {
+        constexpr int ST = decltype(setc)::value;
+        unsigned voff;
+        if (SMALLC) {
+            const bool ok = g_kvalid && rvalid[i] && (unsigned)(ih0[i] + g_kh) < (unsigned)p.H &&
+                            (unsigned)(iw0[i] + g_kw) < (unsigned)p.W;
+            voff = ok ? (unsigned)(roff0[i] + g_coff) : OOB;
+            ra[ST][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, voff, 0, 0));
+        } else {
+            const bool ok = (vmask[i] >> g_bit) & 1u;
+            voff = ok ? (unsigned)((g_src1 ? roff1[i] : roff0[i]) + g_coff) : OOB;
+            ra[ST][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_src1 ? rs1 : rs0, voff, 0, 0));
+        }
+    };
+    auto g_b = [&](int kt, auto setc) {
+        constexpr int ST = decltype(setc)::value;
+        rbh[ST] = __builtin_amdgcn_raw_buffer_load_b128(rwh, woff, kt * (BK * 2), 0);
+        rbl[ST] = __builtin_amdgcn_raw_buffer_load_b128(rwl, woff, kt * (BK * 2), 0);
+    };
+    _Float16 *const a_st = Ah + r0 * LDH + kc * 4;
+    _Float16 *const b_st = Bh + br * LDH + bc * 8;
+    auto s_a = [&](int i, int buf, auto setc) {     // split 4 floats into fp16 hi / lo and write both tiles
+        constexpr int ST = decltype(setc)::value;
+        f32x4 v = ra[ST][i];
+        if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        v = v * ASCALE;
+        const half4 hi = __builtin_convertvector(v, half4);
+        const half4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), half4);
+        _Float16 *dst = a_st + buf * BUF + 32 * i * LDH;
+        *reinterpret_cast<half4 *>(dst) = hi;
+        *reinterpret_cast<half4 *>(dst + BM * LDH) = lo;
+    };
+    auto s_b = [&](int buf, auto setc) {
+        constexpr int ST = decltype(setc)::value;
+        if (bact) {
+            *reinterpret_cast<u32x4 *>(b_st + buf * BUF) = rbh[ST];
+            *reinterpret_cast<u32x4 *>(b_st + buf * BUF + BN * LDH) = rbl[ST];
+        }
+    };
+    auto gload_all = [&](int kt, auto setc) {
+        g_tap(kt);
+#pragma unroll
+        for (int i = 0; i < WM; ++i) g_a(i, setc);
+        g_b(kt < nkt ? kt : nkt - 1, setc);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+    const int nk = kt1 - kt0;
+    if (nk > 0) {
+        gload_all(kt0, I0{});
+        gload_all(kt0 + 1, I1{});
+#pragma unroll
+        for (int i = 0; i < WM; ++i) s_a(i, 0, I0{});
+        s_b(0, I0{});
+    }
+    __syncthreads();
+
+    // fragment addresses: lane (r = lane&31, h = lane>>5) reads 8 halfs at k = 16 ks + 8 h of row r
+    const int arow = (wm * 32 + (lane & 31)) * LDH + (lane >> 5) * 8;
+    const int brow = (wn * 32 + (lane & 31)) * LDH + (lane >> 5) * 8;
+    auto iteration = [&](int it, auto gsc) {
+        constexpr int GS = decltype(gsc)::value;
+        using SS = std::integral_constant<int, GS ^ 1>;
+        constexpr int buf = GS;
+        const int kt2 = kt0 + it + 2;
+        const int kt2c = kt2 < nkt ? kt2 : nkt - 1;
+        const _Float16 *ah = Ah + buf * BUF + arow, *al = ah + BM * LDH;
+        const _Float16 *bh = Bh + buf * BUF + brow, *bl = bh + BN * LDH;
+        half8 fah[2], fal[2], fbh[2], fbl[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            fah[ks] = *reinterpret_cast<const half8 *>(ah + 16 * ks);
+            fbh[ks] = *reinterpret_cast<const half8 *>(bh + 16 * ks);
+            fal[ks] = *reinterpret_cast<const half8 *>(al + 16 * ks);
+            fbl[ks] = *reinterpret_cast<const half8 *>(bl + 16 * ks);
+        }
+        // staging for the following tiles is issued between the MFMAs (same scheme as the fp32 kernel)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[0], fbh[0], acc, 0, 0, 0);
+        g_tap(kt2);
+        __builtin_amdgcn_sched_barrier(0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[1], fbh[1], acc, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < WM; ++i) g_a(i, gsc);
+        g_b(kt2c, gsc);
+        __builtin_amdgcn_sched_barrier(0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[0], fbl[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[1], fbl[1], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[0], fbh[0], acc, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < WM; ++i) s_a(i, buf ^ 1, SS{});
+        __builtin_amdgcn_sched_barrier(0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[1], fbh[1], acc, 0, 0, 0);
+        s_b(buf ^ 1, SS{});
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+    };
+    int it = 0;
+    for (; it + 1 < nk; it += 2) {
+        iteration(it, I0{});
+        iteration(it + 1, I1{});
+    }
+    if (it < nk) iteration(it, I0{});
+
+    // ---- epilogue: undo the power-of-two operand scaling, then bias / residual / ReLU (fp32)
+    const int n = tn * BN + wn * 32 + (lane & 31);
+    if (n >= p.N) return;
+    const float osc = p.oscale[n];
+    const int mbase = tm * BM + wm * 32 + 4 * (lane >> 5);
+    if (p.splitk > 1) {
+        float *dst = p.partial + (long)split * p.M * p.N;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mbase + (r & 3) + 8 * (r >> 2);
+            if (m < p.M) dst[(long)m * p.N + n] = acc[r] * osc;
+        }
+        return;
+    }
+    const float bv = p.bias ? p.bias[n] : 0.f;
+    const bool needb = p.res != nullptr || p.y_bs != 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = mbase + (r & 3) + 8 * (r >> 2);
+        if (m < p.M) {
+            float v = acc[r] * osc + bv;
+            long yo = (long)m * p.N + n;
+            if (needb) {
+                const int b = p.B == 1 ? 0 : m / ohw;
+                const long po = (long)(m - b * ohw) * p.N + n;
+                if (p.res) v += p.res[(long)b * p.res_bs + po];
+                if (p.y_bs) yo = (long)b * p.y_bs + po;
+            }
+            if (p.relu_out) v = fmaxf(v, 0.f);
+            p.y[yo] = v;
+        }
+    }
+}
+
+void conv_f16x3_launch(const ConvP &p, int tiles_n, int ntile, int per, dim3 grid, hipStream_t s, hipEvent_t e0,
+                       hipEvent_t e1) {
+    const bool narrow = p.N <= 32;
+    const int BM = narrow ? 128 : 64, BN = narrow ? 32 : 64;
+    const size_t lds = (size_t)2 * 2 * (BM + BN) * LDH * sizeof(_Float16);
+    const bool smallc = (p.Cin % 32) != 0 || (p.x1 && (p.c0 % 32) != 0) || p.KH * p.KW > 32;
+#define STCN_LAUNCH(WM_, WN_, SC_, RL_)                                                                                 \
+    do {                                                                                                                 \
+        if (e0) hipExtLaunchKernelGGL((conv_gemm_f16x3_kernel<WM_, WN_, SC_, RL_>), grid, dim3(256), lds, s, e0, e1, 0,  \
+                                      p, tiles_n, ntile, per);                                                           \
+        else hipLaunchKernelGGL((conv_gemm_f16x3_kernel<WM_, WN_, SC_, RL_>), grid, dim3(256), lds, s, p, tiles_n,       \
+                                ntile, per);                                                                             \
+    } while (0)
+    const int key = (narrow ? 4 : 0) | (smallc ? 2 : 0) | (p.relu_in ? 1 : 0);
+    switch (key) {
+        case 0: STCN_LAUNCH(2, 2, false, false); break;
+        case 1: STCN_LAUNCH(2, 2, false, true); break;
+        case 2: STCN_LAUNCH(2, 2, true, false); break;
+        case 3: STCN_LAUNCH(2, 2, true, true); break;
+        case 4: STCN_LAUNCH(4, 1, false, false); break;
+        case 5: STCN_LAUNCH(4, 1, false, true); break;
+        case 6: STCN_LAUNCH(4, 1, true, false); break;
+        default: STCN_LAUNCH(4, 1, true, true); break;
+    }
+#undef STCN_LAUNCH
+}
+
+}  // namespace stcn

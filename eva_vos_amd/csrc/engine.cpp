@@ -3,6 +3,7 @@
 // Reference behaviour: mivos/inference_core.py (InferenceCore), mivos/model/propagation/*.py.
 #include "engine.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -90,6 +91,31 @@ static int upload(Model &m, const std::vector<float> &h, float **dev) {
     return STCN_OK;
 }
 
+int make_f16_split(Model &m, ConvW &cw, const std::vector<float> &w) {
+    std::vector<uint16_t> hi((size_t)cw.cout * cw.Kp), lo((size_t)cw.cout * cw.Kp);
+    std::vector<float> osc(cw.cout);
+    for (int n = 0; n < cw.cout; ++n) {
+        float mx = 0.f;
+        for (int k = 0; k < cw.Kp; ++k) mx = std::max(mx, std::fabs(w[(size_t)n * cw.Kp + k]));
+        int sh = 0;
+        if (mx > 0.f) { sh = (int)std::floor(std::log2(1024.f / mx)); sh = std::min(40, std::max(-40, sh)); }
+        osc[n] = std::ldexp(1.f, -sh) / CONV_F16_ASCALE;
+        for (int k = 0; k < cw.Kp; ++k) {
+            const float v = std::ldexp(w[(size_t)n * cw.Kp + k], sh);
+            const _Float16 h = (_Float16)v;
+            const _Float16 l = (_Float16)(v - (float)h);
+            std::memcpy(&hi[(size_t)n * cw.Kp + k], &h, 2);
+            std::memcpy(&lo[(size_t)n * cw.Kp + k], &l, 2);
+        }
+    }
+    for (auto pr : {std::make_pair(&hi, &cw.w_hi), std::make_pair(&lo, &cw.w_lo)}) {
+        HIPCHK(hipMalloc((void **)pr.second, pr.first->size() * 2));
+        m.allocs.push_back(*pr.second);
+        HIPCHK(hipMemcpy(*pr.second, pr.first->data(), pr.first->size() * 2, hipMemcpyHostToDevice));
+    }
+    return upload(m, osc, &cw.oscale);
+}
+
 static int add_convs(Model &m, const std::map<std::string, HostT> &sd) {
     for (auto &kv : sd) {
         const std::string &name = kv.first;
@@ -132,6 +158,7 @@ static int add_convs(Model &m, const std::map<std::string, HostT> &sd) {
         if (rc) return rc;
         rc = upload(m, bias, &cw.bias);
         if (rc) return rc;
+        if (m.precision == 1 && cout > 1 && (rc = make_f16_split(m, cw, w))) return rc;
         cw.bias0 = bias[0];
         m.conv[pre] = cw;
         // Convs over a channel concat [per-object part | frame-only part]: conv is linear in the input
@@ -156,6 +183,7 @@ static int add_convs(Model &m, const std::map<std::string, HostT> &sd) {
                                     wt.p[(((size_t)n * cin + c) * kh + y) * kw + x] * scale[n];
                 std::vector<float> bb = part ? bias : std::vector<float>(cout, 0.f);
                 if ((rc = upload(m, ww, &pw.w)) || (rc = upload(m, bb, &pw.bias))) return rc;
+                if (m.precision == 1 && (rc = make_f16_split(m, pw, ww))) return rc;
                 pw.bias0 = bb[0];
                 m.conv[pre + (part ? "#b" : "#a")] = pw;
             }
@@ -279,7 +307,9 @@ int run_conv(const Model &m, Work &w, hipStream_t s, const char *name, const flo
     p.x1_bytes = x1 ? (unsigned)(((bs1 ? (long)B * bs1 : (long)H * W * c1)) * 4) : 0u;
     p.w_bytes = (unsigned)((long)cw.cout * cw.Kp * 4);
     if (x1 && ((cw.cin_p % 32) || (c0 % 32) || cw.kh * cw.kw > 32)) { set_error("conv '%s': two-source input needs 32-aligned channel splits", name); return STCN_E_INVALID; }
-    p.w = cw.w; p.bias = cw.bias; p.res = res; p.res_bs = res_bs; p.y = y; p.y_bs = y_bs;
+    p.w = cw.w; p.w_hi = cw.w_hi; p.w_lo = cw.w_lo; p.oscale = cw.oscale;
+    p.mode = (m.precision == 1 && cw.w_hi) ? 1 : 0;
+    p.bias = cw.bias; p.res = res; p.res_bs = res_bs; p.y = y; p.y_bs = y_bs;
     p.relu_in = relu_in; p.relu_out = relu_out;
     p.splitk = force_splitk > 0 ? force_splitk : conv_choose_splitk(p);
     while (p.splitk > 1 && (size_t)p.splitk * p.M * p.N > w.splitk_floats) --p.splitk;
@@ -473,7 +503,7 @@ using namespace stcn;
 extern "C" {
 
 const char *stcn_last_error(void) { return stcn::get_error(); }
-const char *stcn_version(void) { return "stcn_hip 0.1 (gfx950, fp32 MFMA)"; }
+const char *stcn_version(void) { return "stcn_hip 0.2 (gfx950; conv modes: fp32 MFMA, f16x3 split)"; }
 
 int stcn_model_create(int device, const stcn_weight_desc *prop, int n_prop, const stcn_weight_desc *fuse, int n_fuse,
                       stcn_model **out) {
@@ -481,6 +511,8 @@ int stcn_model_create(int device, const stcn_weight_desc *prop, int n_prop, cons
     HIPCHK(hipSetDevice(device));
     stcn_model *mm = new stcn_model();
     mm->m.device = device;
+    const char *prec = getenv("STCN_PRECISION");
+    mm->m.precision = (prec && std::string(prec) == "f16x3") ? 1 : 0;
     const int rc = build_model(mm->m, prop, n_prop, fuse, n_fuse);
     if (rc) { stcn_model_destroy(mm); return rc; }
     *out = mm;
@@ -562,6 +594,9 @@ static int engine_alloc_common(stcn_engine *e) {
     const char *la = getenv("STCN_LOOKAHEAD");
     e->lookahead = la ? atoi(la) : 2;
     if (e->T > e->n_slots) e->lookahead = 0;
+    // f16x3 mode is only validated for serial execution (run-to-run differences were observed
+    // when its kernels overlapped with the memory read on another stream)
+    if (e->model->precision == 1) e->lookahead = 0;
     if (e->lookahead > 0) {
         HIPCHK(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
         RC(e->work_side.init(d.nh, d.nw, 1));
@@ -688,6 +723,7 @@ static int ensure_key(stcn_engine *e, int ti, SlotPtrs *out) {
     return STCN_OK;
 }
 
+static void dbg_sum(stcn_engine *e, const char *tag, int ti, const float *p, size_t n);
 static float *bank_v_slot(stcn_engine *e, int slot) { return e->bank_v + (size_t)slot * e->d.hw16 * 512; }
 
 // write key (from cache) + freshly encoded value of frame ti into bank slot `slot`
@@ -701,8 +737,28 @@ static int bank_insert(stcn_engine *e, int slot, int ti, const SlotPtrs &kf, con
     }
     RC(encode_value(*e->model, e->work, e->stream, e->images4 + (size_t)ti * d.npix * 4, kf.f16, masks, mask_stride,
                     bank_v_slot(e, slot), (long)e->bank_cap * d.hw16 * 512, kf.vd, kf.vc));
+    dbg_sum(e, "value", ti, bank_v_slot(e, slot), (size_t)d.hw16 * 512);
     e->stats.value_enc++;
     return STCN_OK;
+}
+
+// debug aid (STCN_DEBUG_CHECKSUM=1): drain everything and print a checksum of a device buffer
+static void dbg_sum(stcn_engine *e, const char *tag, int ti, const float *p, size_t n) {
+    static const bool on = getenv("STCN_DEBUG_CHECKSUM") != nullptr;
+    if (!on) return;
+    (void)hipDeviceSynchronize();
+    std::vector<float> h(n);
+    (void)hipMemcpy(h.data(), p, n * 4, hipMemcpyDeviceToHost);
+    double s1 = 0, s2 = 0;
+    unsigned long long hsh = 1469598103934665603ull, bag = 0;       // order-sensitive hash / order-free bag sum
+    for (size_t i = 0; i < n; ++i) {
+        unsigned u; memcpy(&u, &h[i], 4);
+        hsh = (hsh ^ u) * 1099511628211ull;
+        bag += (unsigned long long)u * 2654435761ull;
+        if (std::isfinite(h[i])) { s1 += h[i]; s2 += (double)h[i] * h[i] * (1 + (i % 7)); }
+    }
+    fprintf(stderr, "CHK %-10s t=%d %.10e %.10e hash %016llx bag %016llx\n", tag, ti, s1, s2, hsh, bag);
+    (void)e;
 }
 
 // do_pass (inference_core.py:126-191)
@@ -721,6 +777,7 @@ static int do_pass(stcn_engine *e, int idx, bool forward) {
     const long prs = (long)T * d.npix;                      // prob row stride
     Work &w = e->work;
     for (int ti = idx + step; ti != closest; ti += step) {
+        RC(enqueue_key(e, ti));
         for (int a = 1, tj = ti + step; a <= e->lookahead && tj != closest; ++a, tj += step) RC(enqueue_key(e, tj));
         SlotPtrs kf;
         RC(ensure_key(e, ti, &kf));
@@ -730,7 +787,10 @@ static int do_pass(stcn_engine *e, int idx, bool forward) {
             memory_read_launch(e->bank_k, e->bank_msq, kf.k16, N, d.hw16, e->bank_v, (long)e->bank_cap * d.hw16 * 512, k,
                                w.readout, (long)d.hw16 * 512, nullptr, nullptr, MemReadScratch{w.cand_v, w.cand_i, w.gmax, w.tau}, e->stream);
         }
+        dbg_sum(e, "k16", ti, kf.k16, (size_t)d.hw16 * 64);
+        dbg_sum(e, "readout", ti, w.readout, (size_t)k * d.hw16 * 512);
         RC(decode(*e->model, w, e->stream, w.readout, kf.f16_thin, kf.s8, kf.s4, w.agg, d.npix, kf.dthin, kf.cthin));
+        dbg_sum(e, "agg", ti, w.agg, (size_t)(k + 1) * d.npix);
         if (ti != end && std::abs(ti - last_ti) >= e->mem_freq) {
             RC(bank_insert(e, m_front, ti, kf, w.agg + d.npix, d.npix));
             ++m_front;

@@ -14,6 +14,10 @@
 namespace stcn {
 
 void set_error(const char *fmt, ...);
+struct Model;
+struct ConvW;
+// builds the fp16 hi / lo weight arrays + output scales of one conv from its repacked fp32 host weights
+int make_f16_split(Model &m, ConvW &cw, const std::vector<float> &w_host);
 #define HIPCHK(x)                                                                          \
     do {                                                                                   \
         hipError_t e_ = (x);                                                               \
@@ -25,12 +29,15 @@ void set_error(const char *fmt, ...);
 
 struct ConvW {
     float *w = nullptr, *bias = nullptr;   // device: [Cout][Kp], [Cout]
+    uint16_t *w_hi = nullptr, *w_lo = nullptr;   // device: fp16 hi/lo of 2^s_n * w (f16x3 mode)
+    float *oscale = nullptr;               // device: [Cout] 2^-s_n / 4
     float bias0 = 0.f;                     // host copy of bias[0] (Cout == 1 convs)
     int cout = 0, cin = 0, cin_p = 0, kh = 0, kw = 0, K = 0, Kp = 0;
 };
 
 struct Model {
     int device = 0;
+    int precision = 0;                     // 0 = fp32 MFMA, 1 = f16x3 split (env STCN_PRECISION=f16x3)
     std::map<std::string, ConvW> conv;
     CbamW cbam{};
     bool has_fuse = false;

@@ -1,4 +1,6 @@
 // hooks.cpp - stage-level C-ABI entry points used by tests/ and bench.py (see include/stcn_hip.h).
+#include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "engine.h"
@@ -35,6 +37,15 @@ int stcn_test_conv(void *stream, const float *x, const float *wgt, const float *
     HIPCHK(hipMemsetAsync(wpad.p, 0, (size_t)Cout * cw.Kp * 4, s));
     HIPCHK(hipMemcpy2DAsync(wpad.p, (size_t)cw.Kp * 4, wgt, (size_t)cw.K * 4, (size_t)cw.K * 4, Cout, hipMemcpyDeviceToDevice, s));
     cw.w = wpad.p; cw.bias = const_cast<float *>(bias);
+    const char *prec = getenv("STCN_PRECISION");
+    m.precision = (prec && std::string(prec) == "f16x3" && Cout > 1) ? 1 : 0;
+    struct Guard { Model &m; ~Guard() { (void)hipDeviceSynchronize(); for (void *p : m.allocs) (void)hipFree(p); } } guard{m};
+    if (m.precision == 1) {
+        HIPCHK(hipStreamSynchronize(s));
+        std::vector<float> hw((size_t)Cout * cw.Kp);
+        HIPCHK(hipMemcpy(hw.data(), wpad.p, hw.size() * 4, hipMemcpyDeviceToHost));
+        RC(make_f16_split(m, cw, hw));
+    }
     m.conv["t"] = cw;
     Work w;
     w.splitk_floats = (size_t)16 * 1024 * 1024;
@@ -78,6 +89,10 @@ int stcn_bench_conv(void *stream, int B, int H, int W, int Cin, int Cout, int KH
     HIPCHK(hipMemcpy(wt.p, h.data(), h.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemsetAsync(b.p, 0, Cout * 4, s));
     cw.w = wt.p; cw.bias = b.p;
+    const char *prec = getenv("STCN_PRECISION");
+    m.precision = (prec && std::string(prec) == "f16x3" && Cout > 1) ? 1 : 0;
+    struct Guard { Model &m; ~Guard() { (void)hipDeviceSynchronize(); for (void *p : m.allocs) (void)hipFree(p); } } guard{m};
+    if (m.precision == 1) RC(make_f16_split(m, cw, h));
     m.conv["t"] = cw;
     Work w;
     w.splitk_floats = (size_t)32 * 1024 * 1024;

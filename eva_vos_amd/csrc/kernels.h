@@ -19,6 +19,9 @@ struct ConvP {
     int M, N;               // M = B*OH*OW rows, N = Cout
     int K, Kp;              // K = KH*KW*Cin, Kp = K rounded up to 32 (weights zero-padded)
     const float *w;         // [N][Kp], k ordered (kh, kw, cin)
+    const uint16_t *w_hi, *w_lo;   // f16x3 mode: fp16 hi / lo halves of 2^s_n * w, same [N][Kp] layout
+    const float *oscale;    // f16x3 mode: per output channel 2^-s_n / 4 (undoes the operand pre-scaling)
+    int mode;               // 0 = exact fp32 MFMA, 1 = f16x3 split on the f16 MFMA pipe
     const float *bias;      // [N] or nullptr
     const float *res;       // residual [B][OH*OW][N] or nullptr
     long res_bs;            // batch stride of res (0 = broadcast)
@@ -34,6 +37,9 @@ int  conv_choose_splitk(const ConvP &p);
 // (hipExtLaunchKernelGGL: kernel begin/end timestamps, no extra barrier packets)
 void conv_launch(const ConvP &p, hipStream_t s, hipEvent_t *ev_gemm = nullptr, hipEvent_t *ev_red = nullptr);
 size_t conv_workspace_floats(const ConvP &p);
+void conv_f16x3_launch(const ConvP &p, int tiles_n, int ntile, int per, dim3 grid, hipStream_t s, hipEvent_t e0,
+                       hipEvent_t e1);
+static constexpr float CONV_F16_ASCALE = 4.f;
 
 // Cout == 1 convolution (decoder.pred, FusionNet.final_conv): one dot product per output pixel.
 // x [B,H,W,C] (C multiple of 4), w [KH*KW*C], y [B*H*W]; stride 1, "same" padding.

@@ -126,3 +126,20 @@ def test_config3_multi_object_full_bank_properties(nets):
     assert (prob[:, 1:].sum(0) - 1).abs().max() < 1e-5
     assert set(np.unique(outs[0][0])) <= set(range(k + 1))
     assert all((outs[0][0][1:] == o).mean() > 0.01 for o in range(1, k + 1))
+
+
+@pytest.mark.parametrize("tag", ["seqA", "seqC"])
+def test_f16x3_mode_matches_reference_goldens(tag, weights, monkeypatch):
+    """Opt-in f16x3 conv mode (fp16 hi/lo split on the f16 MFMA pipe, fp32 accumulation, serial execution):
+    held to the SAME tolerances as the exact-fp32 default."""
+    from eva_vos_amd.params import FusionNet, PropagationNetwork
+    monkeypatch.setenv("STCN_PRECISION", "f16x3")
+    p, f = PropagationNetwork(), FusionNet()          # fresh containers -> a fresh model handle in f16x3 mode
+    p.load_state_dict(weights[0])
+    f.load_state_dict(weights[1])
+    g = load_golden(tag)
+    outs = run_sequence(make_core((p.eval(), f.eval())), tag, g)
+    check_sequence_against_golden(outs, tag, g, prob_atol=3e-3)
+    # and it is deterministic
+    outs2 = run_sequence(make_core((p, f)), tag, g)
+    assert all(np.array_equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(outs, outs2))
