@@ -11,6 +11,8 @@ if ROOT not in sys.path:
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 torch.set_grad_enabled(False)
+# the CPU oracle thrashes with hundreds of intra-op threads on the GPU box's host
+torch.set_num_threads(min(32, os.cpu_count() or 1))
 
 
 def pytest_configure(config):

@@ -143,3 +143,25 @@ def test_f16x3_mode_matches_reference_goldens(tag, weights, monkeypatch):
     # and it is deterministic
     outs2 = run_sequence(make_core((p, f)), tag, g)
     assert all(np.array_equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(outs, outs2))
+
+
+def test_long_clip_exercises_cache_flush_policy(nets, weights):
+    """T = 112 > 106 cache slots: the reference flushes its key cache when it holds more than 105 frames
+    (inference_core.py:118-119); the engine mirrors that (and disables key look-ahead).  Round 2 then has
+    key-encoder misses again.  Masks must still match the oracle, which implements the same policy."""
+    T, H, W = 112, 112, 128
+    img = synth.synthetic_clip(T, H, W, seed=9)
+    msk = synth.synthetic_mask(T, H, W, 1, seed=10)
+    core = make_core(nets)(img, 1, 5)
+    orc = O.OracleCore(weights[0], weights[1], img, 1, mem_freq=5)
+    a, b = core.interact(msk[:, 0], 0), orc.interact(msk[:, 0], 0)
+    s1 = core.stats()
+    assert s1["key_miss"] == T and s1["frames"] == T - 1
+    assert iou(a > 0, b > 0) >= 1 - 1e-3
+    a2, b2 = core.interact(msk[:, 60], 60), orc.interact(msk[:, 60], 60)
+    s2 = core.stats()
+    assert s2["key_miss"] > 0, "after a flush some frames must be re-encoded"
+    assert s2["fused"] == 59 and s2["frames"] == T - 2
+    assert iou(a2 > 0, b2 > 0) >= 1 - 1e-3
+    d = (core.prob.cpu() - orc.prob).abs().numpy()
+    assert np.quantile(d, 0.999) < 3e-3
