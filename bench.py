@@ -132,39 +132,46 @@ def main():
         with torch.cuda.stream(streams[lane]):
             return InferenceCore(prop, fuse, img, K_OBJ, mem_freq=a.mem_freq)
 
-    warm = [make(i % S) for i in range(a.warmup)]
-    timed = [make(j % S) for j in range(a.steps)]           # video j runs on lane j % S
+    # A bounded pool of engines (each ~4.6 GB at T=66) serves any --steps: lane l owns engines pool[l]; a video
+    # takes the lane's next engine and resets it first (reset = what a fresh InferenceCore would hold).
+    per_lane = 2
+    pool = [[make(l) for _ in range(per_lane)] for l in range(S)]
     torch.cuda.synchronize()
-    for i, e in enumerate(warm):
-        with torch.cuda.stream(streams[i % S]):
+    for i in range(a.warmup):
+        l = i % S
+        with torch.cuda.stream(streams[l]):
+            e = pool[l][(i // S) % per_lane]
+            e.reset()
             e.interact(mask0, 0, scribble=K_OBJ > 1)
             if a.r2:
                 e.interact(mask_mid, T // 2, scribble=K_OBJ > 1)
     torch.cuda.synchronize()
-    del warm
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_lane(lane, mask, idx):
-        """Host thread `lane`: its videos one after another on its own stream (ctypes releases the GIL)."""
+    def run_lane(lane, mask, idx, fresh):
+        """Host thread `lane`: its videos (j = lane, lane+S, ...) one after another on its own stream
+        (ctypes releases the GIL)."""
         torch.cuda.set_device(local)
         fr, out = 0, None
         with torch.cuda.stream(streams[lane]):
-            for j in range(lane, len(timed), S):
-                e = timed[j]
+            for n, j in enumerate(range(lane, a.steps, S)):
+                e = pool[lane][n % per_lane]
+                if fresh:
+                    e.reset()
                 out = e.interact(mask, idx, scribble=K_OBJ > 1)
                 fr += e.stats()["frames"]
         return fr, out
 
-    def run_all(mask, idx):
+    def run_all(mask, idx, fresh=True):
         if S == 1:
-            return [run_lane(0, mask, idx)]
+            return [run_lane(0, mask, idx, fresh)]
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(S) as ex:
-            return list(ex.map(lambda l: run_lane(l, mask, idx), range(S)))
+            return list(ex.map(lambda l: run_lane(l, mask, idx, fresh), range(S)))
 
     barrier()
     t0 = time.perf_counter()
@@ -209,7 +216,7 @@ def main():
     if a.r2:
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        res2 = run_all(mask_mid, T // 2)
+        res2 = run_all(mask_mid, T // 2, fresh=False)     # second interaction on the engines' last videos
         torch.cuda.synchronize()
         r2 = sum(r[0] for r in res2) / (time.perf_counter() - t1)
 
@@ -224,7 +231,6 @@ def main():
         dt_all, frames_all = dt, float(frames)
 
     # per-video J&F rows of the last video of each rank, gathered once (the path's only exchange step)
-    lw, uw, lh, uh = timed[-1].pad
     sc = metrics.sequence_scores(gt[0, :, 0].numpy() > 0.5, last == 1, every=max(1, T // 6))
     row = np.array([[rank, sc[1:, 1].mean(), sc[1:, 2].mean(), sc[1:, 3].mean()]], np.float32)
     rows = shard.gather_rows(row, 4)
@@ -237,7 +243,7 @@ def main():
             "ms_per_step": 1e3 * dt_all / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"DAVIS-17-val-shaped {H}x{W} (padded {timed[0].nh}x{timed[0].nw}) {'single' if K_OBJ == 1 else K_OBJ}-object "
+            "config": {"workload": f"DAVIS-17-val-shaped {H}x{W} (padded {pool[0][0].nh}x{pool[0][0].nw}) {'single' if K_OBJ == 1 else K_OBJ}-object "
                                    f"STCN propagate: fresh engine, interact(mask,0), T={T} frames/video, "
                                    f"mem_freq={a.mem_freq}, top_k=50; one video per step per GPU",
                        "frames_per_step": T - 1, "videos_per_gpu": a.steps, "sharding": f"videos x{world}", "streams_per_gpu": S,

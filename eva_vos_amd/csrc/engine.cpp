@@ -527,6 +527,7 @@ int stcn_model_destroy(stcn_model *m) {
 }
 
 // ---- engine -------------------------------------------------------------------------------------
+static int engine_init_outputs(stcn_engine *e);
 static int eng_alloc(stcn_engine *e, void **p, size_t bytes) {
     HIPCHK(hipMalloc(p, bytes));
     e->allocs.push_back(*p);
@@ -630,13 +631,33 @@ int stcn_engine_create(const stcn_model *m, int T, int H, int W, int k, int mem_
     const Dims &d = e->d;
     for (int t = 0; t < T; ++t)
         pack_image_launch(images_dev + (size_t)t * 3 * H * W, e->images4 + (size_t)t * d.npix * 4, H, W, nh, nw, e->lw, e->lh, e->stream);
-    // prob: bg row 1e-7, object rows 0 (inference_core.py:86-87)
-    fill_launch(prob_dev, 1e-7f, (long)T * d.npix, e->stream);
-    fill_launch(prob_dev + (size_t)T * d.npix, 0.f, (long)k * T * d.npix, e->stream);
-    HIPCHK(hipMemsetAsync(masks_dev, 0, (size_t)T * d.npix, e->stream));
+    if ((rc = engine_init_outputs(e))) { stcn_engine_destroy(e); return rc; }
     HIPCHK(hipStreamSynchronize(e->stream));   // images_dev may be released by the caller after return
     *out = e;
     return STCN_OK;
+}
+
+static int engine_init_outputs(stcn_engine *e) {
+    const Dims &d = e->d;
+    // prob: bg row 1e-7, object rows 0 (inference_core.py:86-87)
+    fill_launch(e->prob, 1e-7f, (long)e->T * d.npix, e->stream);
+    fill_launch(e->prob + (size_t)e->T * d.npix, 0.f, (long)e->k * e->T * d.npix, e->stream);
+    HIPCHK(hipMemsetAsync(e->masks, 0, (size_t)e->T * d.npix, e->stream));
+    return STCN_OK;
+}
+
+int stcn_engine_reset(stcn_engine *e) {
+    if (!e) { set_error("stcn_engine_reset: null engine"); return STCN_E_INVALID; }
+    HIPCHK(hipSetDevice(e->model->device));
+    if (e->side) HIPCHK(hipStreamSynchronize(e->side));
+    e->interacted.clear();
+    e->n_certain = 0;
+    e->n_cached = 0;
+    std::fill(e->slot_of.begin(), e->slot_of.end(), -1);
+    std::fill(e->vparts_ready.begin(), e->vparts_ready.end(), 0);
+    std::fill(e->key_pending.begin(), e->key_pending.end(), 0);
+    e->stats = stcn_stats{};
+    return engine_init_outputs(e);
 }
 
 int stcn_engine_destroy(stcn_engine *e) {

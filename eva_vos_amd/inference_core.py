@@ -114,6 +114,14 @@ class InferenceCore:
             self.np_masks = out.cpu().numpy().astype(np.uint8)     # D2H sync, as the reference's .cpu()
         return self.np_masks
 
+    def reset(self):
+        """Forget all interactions / cached features (same clip): equivalent to constructing a new
+        InferenceCore on the same images, without re-allocating device memory."""
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().stcn_engine_reset(self._engine), "stcn_engine_reset")
+        self.interacted = set()
+        self.np_masks = np.zeros((self.t, self.h, self.w), dtype=np.uint8)
+
     def get_image_buffered(self, idx):
         lw, uw, lh, uh = self.pad
         return torch.nn.functional.pad(self._images_unpadded[:, idx], (lw, uw, lh, uh))

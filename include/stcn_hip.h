@@ -73,6 +73,12 @@ int stcn_engine_create(const stcn_model *m, int T, int H, int W, int k, int mem_
                        stcn_engine **out);
 int stcn_engine_destroy(stcn_engine *e);
 
+/* Back to the state right after stcn_engine_create (same clip): forgets interactions, certain memory and the
+ * key-feature cache, re-initialises prob / masks.  Lets a driver reuse one engine's device memory for the
+ * next sample of the same shape instead of re-allocating ~4.6 GB.  (No reference counterpart: the reference
+ * constructs a new InferenceCore per sample, interactions/eval.py:99.) */
+int stcn_engine_reset(stcn_engine *e);
+
 /* Deep copy of all engine state (certain memory, key cache, interaction set).  The clone writes to
  * the caller-provided prob/masks buffers, which the caller must have filled with a copy of the
  * source's.  Replaces: copy.deepcopy(processor) (interactions/policies.py:103-104). */

@@ -165,3 +165,17 @@ def test_long_clip_exercises_cache_flush_policy(nets, weights):
     assert iou(a2 > 0, b2 > 0) >= 1 - 1e-3
     d = (core.prob.cpu() - orc.prob).abs().numpy()
     assert np.quantile(d, 0.999) < 3e-3
+
+
+def test_reset_equals_fresh_engine(nets):
+    T, H, W = 6, 112, 144
+    img, msk = synth.synthetic_clip(T, H, W), synth.synthetic_mask(T, H, W, 1)
+    core = make_core(nets)(img, 1, 2)
+    a = core.interact(msk[:, 1], 1).copy()
+    pa = core.prob.clone()
+    core.interact(msk[:, 4], 4)
+    core.reset()
+    assert float(core.prob[1:].abs().max()) == 0.0 and abs(float(core.prob[0].max()) - 1e-7) < 1e-12
+    b = core.interact(msk[:, 1], 1)
+    assert np.array_equal(a, b) and torch.equal(pa, core.prob)
+    assert core.stats()["key_miss"] == T
