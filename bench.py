@@ -231,8 +231,8 @@ def main():
         dt_all, frames_all = dt, float(frames)
 
     # per-video J&F rows of the last video of each rank, gathered once (the path's only exchange step)
-    sc = metrics.sequence_scores(gt[0, :, 0].numpy() > 0.5, last == 1, every=max(1, T // 6))
-    row = np.array([[rank, sc[1:, 1].mean(), sc[1:, 2].mean(), sc[1:, 3].mean()]], np.float32)
+    sc = metrics.sequence_scores_gpu((gt[0, :, 0] > 0.5).cuda(), torch.from_numpy(last == 1).cuda())   # HIP J/F kernel
+    row = np.array([[rank, sc[1:, 0].mean(), sc[1:, 1].mean(), sc[1:, 2].mean()]], np.float32)
     rows = shard.gather_rows(row, 4)
 
     if rank == 0:

@@ -1,4 +1,5 @@
 // hooks.cpp - stage-level C-ABI entry points used by tests/ and bench.py (see include/stcn_hip.h).
+#include <cmath>
 #include <cstdlib>
 #include <string>
 #include <vector>
@@ -215,6 +216,19 @@ int stcn_test_fusion(const stcn_model *m, void *stream, const float *img, const 
     RC(pack_one(img, nh, nw, img4.p, s));
     RC(fusion_logit(m->m, t.w, s, img4.p, prev, curr, attn, nc, nr, logit));
     HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    return STCN_OK;
+}
+
+int stcn_metrics_jf_counts(void *stream, const uint8_t *gt_dev, const uint8_t *pred_dev, int T, int H, int W,
+                           int32_t *counts_dev, uint8_t *scratch_dev) {
+    if (!gt_dev || !pred_dev || !counts_dev || !scratch_dev || T < 1 || H < 2 || W < 2) {
+        set_error("stcn_metrics_jf_counts: bad arguments");
+        return STCN_E_INVALID;
+    }
+    // bound_pix = ceil(0.008 * ||(H, W)||)  (interactions/metrics.py:119-120)
+    const int radius = (int)std::ceil(0.008 * std::sqrt((double)H * H + (double)W * W));
+    jf_counts_launch(gt_dev, pred_dev, T, H, W, radius, scratch_dev, counts_dev, (hipStream_t)stream);
     HIPCHK(hipGetLastError());
     return STCN_OK;
 }

@@ -100,4 +100,10 @@ void pack_fusion_input_launch(const float *img4, const float *prev, const float 
                               const float *attn2, float nc, float nr, long npix, float *out,
                               hipStream_t s);
 
+// ---------------------------------------------------------------- J / F metric counts (interactions/metrics.py)
+// gt, pred uint8 [T,H,W] (non-zero = object); bmap scratch [T*H*W]; counts [T][6] =
+// (intersection, union, gt boundary px, pred boundary px, matched gt boundary px, matched pred boundary px)
+void jf_counts_launch(const uint8_t *gt, const uint8_t *pred, int T, int H, int W, int radius, uint8_t *bmap,
+                      int *counts, hipStream_t s);
+
 }  // namespace stcn

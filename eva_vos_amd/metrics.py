@@ -60,3 +60,46 @@ def sequence_scores(gt: np.ndarray, pred: np.ndarray, every: int = 1) -> np.ndar
         j, f = jaccard(gt[t], pred[t]), f_measure(gt[t], pred[t])
         rows.append((t, j, f, 0.5 * (j + f)))
     return np.asarray(rows, np.float32)
+
+
+# ------------------------------------------------------------------------------------------------ GPU path
+def _scores_from_counts(c: np.ndarray) -> np.ndarray:
+    """[T,6] integer counts -> rows (J, F, J&F) with the reference's special cases (metrics.py:141-158)."""
+    out = np.zeros((c.shape[0], 3), np.float64)
+    for t, (inter, union, n_gt, n_fg, gt_m, fg_m) in enumerate(c.tolist()):
+        j = 0.0 if union == 0 else inter / union
+        if n_fg == 0 and n_gt > 0:
+            p, r = 1.0, 0.0
+        elif n_fg > 0 and n_gt == 0:
+            p, r = 0.0, 1.0
+        elif n_fg == 0 and n_gt == 0:
+            p, r = 1.0, 1.0
+        else:
+            p, r = fg_m / n_fg, gt_m / n_gt
+        f = 0.0 if p + r == 0 else 2 * p * r / (p + r)
+        out[t] = (j, f, 0.5 * (j + f))
+    return out
+
+
+def sequence_scores_gpu(gt, pred):
+    """J, F, J&F per frame on the GPU (HIP kernels behind ``stcn_metrics_jf_counts``).
+    gt, pred: torch uint8/bool tensors [T,H,W] on the same cuda device (non-zero = object).
+    Returns float64 [T,3]; only the 6*T integer counts cross PCIe."""
+    import ctypes as C
+
+    import torch
+
+    from . import _lib
+    gt = (gt != 0).to(torch.uint8).contiguous()
+    pred = (pred != 0).to(torch.uint8).contiguous()
+    assert gt.is_cuda and pred.is_cuda and gt.shape == pred.shape and gt.dim() == 3
+    T, H, W = gt.shape
+    with torch.cuda.device(gt.device):
+        counts = torch.empty((T, 6), dtype=torch.int32, device=gt.device)
+        scratch = torch.empty((T * H * W,), dtype=torch.uint8, device=gt.device)
+        _lib.check(_lib.lib().stcn_metrics_jf_counts(C.c_void_p(torch.cuda.current_stream().cuda_stream),
+                                                     C.c_void_p(gt.data_ptr()), C.c_void_p(pred.data_ptr()), T, H, W,
+                                                     C.c_void_p(counts.data_ptr()), C.c_void_p(scratch.data_ptr())),
+                   "stcn_metrics_jf_counts")
+        c = counts.cpu().numpy()
+    return _scores_from_counts(c)

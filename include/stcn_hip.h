@@ -162,6 +162,18 @@ int stcn_get_kernel_flops(const stcn_engine *e, double *flops /*[STCN_K_COUNT]*/
 /* Algorithmic HBM bytes (every operand of every launch once; conv class only) of the last interact(). */
 int stcn_get_kernel_bytes(const stcn_engine *e, double *bytes /*[STCN_K_COUNT]*/);
 
+/* ---- caller-side metric -------------------------------------------------------
+ * Integer counts behind J (region IoU) and F (boundary measure) for T frames, on the device.
+ *   gt_dev, pred_dev : uint8 [T,H,W], non-zero = object (unpadded masks)
+ *   counts_dev       : int32 [T,6] = intersection, union, gt boundary px, pred boundary px,
+ *                      gt boundary px matched within the disk, pred boundary px matched within the disk
+ *   scratch_dev      : uint8 [T*H*W]
+ * The disk radius is ceil(0.008 * ||(H,W)||) as in the reference.  Enqueues on `stream`, no sync.
+ * Replaces: get_j_and_f / f_measure / _seg2bmap (interactions/metrics.py:24-34,38-97,100-160) as called per
+ * frame per round by eval_processor_metric (interactions/eval.py:50-79). */
+int stcn_metrics_jf_counts(void *stream, const uint8_t *gt_dev, const uint8_t *pred_dev, int T, int H, int W,
+                           int32_t *counts_dev, uint8_t *scratch_dev);
+
 #ifdef __cplusplus
 }
 #endif

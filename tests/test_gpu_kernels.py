@@ -123,3 +123,30 @@ def test_attention_read_matches_oracle():
     out = torch.empty(kk, 2, 16 * h, 16 * w, device="cuda")
     call("stcn_test_attention", stream(), dev(mk), dev(qk), dev(pos), dev(neg), kk, 16 * h, 16 * w, out)
     assert (out.cpu() - ref).abs().max() < 1e-5
+
+
+def test_gpu_j_and_f_equal_the_cpu_metrics_exactly():
+    """J / F counts on the GPU are integer-exact: scores must equal the NumPy/SciPy implementation bit for bit
+    (same special cases), incl. empty masks, frame-edge objects and a 480x854 frame (disk radius 8)."""
+    import numpy as np
+    from eva_vos_amd import metrics
+    rng = np.random.default_rng(5)
+    for (T, H, W) in [(5, 60, 90), (3, 480, 854)]:
+        yy, xx = np.mgrid[0:H, 0:W]
+        gt = np.zeros((T, H, W), bool)
+        pr = np.zeros((T, H, W), bool)
+        for t in range(T):
+            cy, cx = H * (0.3 + 0.1 * t), W * (0.4 + 0.05 * t)
+            gt[t] = ((yy - cy) / (0.2 * H)) ** 2 + ((xx - cx) / (0.25 * W)) ** 2 < 1
+            pr[t] = ((yy - cy - 3) / (0.22 * H)) ** 2 + ((xx - cx + 4) / (0.2 * W)) ** 2 < 1
+            pr[t] ^= rng.random((H, W)) < 0.002                      # speckle noise -> extra boundaries
+        pr[0] = False                                                # n_fg == 0, n_gt > 0
+        gt[1, :, :] = False                                          # n_gt == 0, n_fg > 0
+        gt[2, -10:, -15:] = True                                     # object touching the last row / column
+        got = metrics.sequence_scores_gpu(torch.from_numpy(gt).cuda(), torch.from_numpy(pr).cuda())
+        for t in range(T):
+            j, f = metrics.jaccard(gt[t], pr[t]), metrics.f_measure(gt[t], pr[t])
+            assert got[t, 0] == j and got[t, 1] == f, (T, H, W, t, got[t], j, f)
+    both_empty = metrics.sequence_scores_gpu(torch.zeros(1, 40, 40, dtype=torch.uint8).cuda(),
+                                             torch.zeros(1, 40, 40, dtype=torch.uint8).cuda())
+    assert both_empty[0].tolist() == [0.0, 1.0, 0.5]

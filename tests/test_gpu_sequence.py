@@ -179,3 +179,25 @@ def test_reset_equals_fresh_engine(nets):
     b = core.interact(msk[:, 1], 1)
     assert np.array_equal(a, b) and torch.equal(pa, core.prob)
     assert core.stats()["key_miss"] == T
+
+
+@pytest.mark.parametrize("T,idx,k,mf", [(1, 0, 1, 5), (2, 1, 1, 5), (5, 4, 1, 1), (5, 0, 2, 1), (6, 3, 2, 3)])
+def test_edge_shapes_match_oracle(T, idx, k, mf, nets, weights):
+    """Degenerate clips and interaction positions: single frame (nothing to propagate), interaction on the
+    last frame (forward pass empty), k = 2 through the scribble path, mem_freq = 1 (every frame memorised)."""
+    H, W = 112, 128
+    img = synth.synthetic_clip(T, H, W, seed=21)
+    msk = synth.synthetic_mask(T, H, W, k, seed=22)
+    m = msk[:, idx]
+    if k > 1:
+        m = torch.cat([1 - m.sum(0, keepdim=True).clamp(0, 1), m], 0)
+    core = make_core(nets)(img, k, mf)
+    orc = O.OracleCore(weights[0], weights[1], img, k, mem_freq=mf)
+    a, b = core.interact(m, idx, scribble=k > 1), orc.interact(m, idx, scribble=k > 1)
+    assert a.shape == b.shape == (T, H, W)
+    for o in range(1, k + 1):
+        assert iou(a == o, b == o) >= 1 - 5e-3
+    d = (core.prob.cpu() - orc.prob).abs().numpy()
+    assert np.quantile(d, 0.999) < 3e-3
+    s = core.stats()
+    assert s["frames"] == T - 1 and s["fused"] == 0
