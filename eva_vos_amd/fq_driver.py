@@ -1,0 +1,228 @@
+"""Frame-quality dataset generation on the HIP engine, sharded over the GPUs of one node (BASELINE config 4).
+
+Own counterpart of the reference driver ``generate_fq_dataset.py:60-86`` and what it calls - the clip loader
+``datasets/annotation_dataset.py:80-132`` (one sample per (video, object), ImageNet normalisation
+``datasets/range_transform.py:3-6``), the oracle policy ``interactions/mask.py:113-156`` (8 rounds: annotate
+the worst frame by J with its ground-truth mask), the per-frame evaluation ``interactions/eval.py:27-81`` and
+the writer ``util/fq_dataset.py:50-91`` (224x224 nearest-resized masks as PNG + a CSV of
+``state_name, ious, selected_frame``).  Differences by design:
+
+* samples are assigned to ranks with an LPT schedule over their frame counts instead of ``--min-idx/--max-idx``;
+  propagation has no collective; ONE gather of fixed-width rows at the end (RCCL over xGMI), rank 0 writes the CSV;
+* a decoded clip is cached per video and reused for all its objects (the reference re-decodes it per object);
+* J is computed on the GPU from the engine's mask tensor (``stcn_metrics_jf_counts``), only counts cross PCIe.
+
+Usage:  python -m eva_vos_amd.fq_driver --root data/MOSE --imset data/MOSE/ImageSets/subset_train_4.txt --out FQ_DB
+        (multi-GPU: python -m torch.distributed.run --nproc-per-node N -m eva_vos_amd.fq_driver ...)
+"""
+from __future__ import annotations
+
+import argparse
+import csv
+import os
+from typing import Dict, List
+
+import numpy as np
+import torch
+from PIL import Image
+
+from . import metrics, shard
+
+MEAN = np.array([0.485, 0.456, 0.406], np.float32)
+STD = np.array([0.229, 0.224, 0.225], np.float32)
+NO_OBJECT = 20.0          # the reference's token for frames without the object (interactions/eval.py:67)
+
+
+# ------------------------------------------------------------------------------------------------ data
+class ClipDataset:
+    """DAVIS/MOSE directory layout: JPEGImages/480p/<video>/%05d.jpg, Annotations/480p/<video>/%05d.png
+    (palette index = object id).  One sample per (video, object), named ``<video>__<obj>``."""
+
+    def __init__(self, root: str, imset: str, resolution: str = "480p"):
+        self.image_dir = os.path.join(root, "JPEGImages", resolution)
+        self.mask_dir = os.path.join(root, "Annotations", resolution)
+        self.samples: List[tuple] = []          # (video, object id, frames)
+        for line in open(imset):
+            v = line.strip()
+            if not v:
+                continue
+            first = np.array(Image.open(os.path.join(self.mask_dir, v, "00000.png")).convert("P"))
+            n = len(os.listdir(os.path.join(self.image_dir, v)))
+            for obj in range(1, int(first.max()) + 1):
+                self.samples.append((v, obj, n))
+        self._cache: Dict[str, tuple] = {}
+
+    def __len__(self):
+        return len(self.samples)
+
+    def name(self, i):
+        v, o, _ = self.samples[i]
+        return f"{v}__{o}"
+
+    def _clip(self, video: str, n: int):
+        if video not in self._cache:
+            self._cache.clear()                  # keep one decoded clip (samples of a video are adjacent)
+            rgb = np.stack([np.asarray(Image.open(os.path.join(self.image_dir, video, f"{f:05d}.jpg")).convert("RGB"))
+                            for f in range(n)]).astype(np.float32) / 255.0
+            lab = np.stack([np.array(Image.open(os.path.join(self.mask_dir, video, f"{f:05d}.png")).convert("P"),
+                                     dtype=np.uint8) for f in range(n)])
+            rgb = ((rgb - MEAN) / STD).transpose(0, 3, 1, 2)
+            self._cache[video] = (torch.from_numpy(np.ascontiguousarray(rgb)), torch.from_numpy(lab))
+        return self._cache[video]
+
+    def __getitem__(self, i):
+        v, obj, n = self.samples[i]
+        rgb, lab = self._clip(v, n)
+        gt = (lab == obj).float()[None, :, None]              # [1,T,1,H,W], no bg channel (reference layout)
+        return {"rgb": rgb[None], "gt": gt, "name": self.name(i), "video": v, "num_frames": n}
+
+
+def make_synthetic_tree(root: str, videos: Dict[str, tuple], seed: int = 0) -> str:
+    """Write a tiny DAVIS-layout dataset (for tests / smoke runs).  videos: name -> (T, H, W, n_objects)."""
+    from . import synth
+    names = []
+    for vi, (name, (T, H, W, k)) in enumerate(videos.items()):
+        os.makedirs(os.path.join(root, "JPEGImages", "480p", name), exist_ok=True)
+        os.makedirs(os.path.join(root, "Annotations", "480p", name), exist_ok=True)
+        img = synth.synthetic_clip(T, H, W, seed=seed + vi)[0].numpy()
+        msk = synth.synthetic_mask(T, H, W, k, seed=seed + vi)[:, :, 0].numpy()
+        for t in range(T):
+            rgb = np.clip((img[t].transpose(1, 2, 0) * STD + MEAN) * 255, 0, 255).astype(np.uint8)
+            Image.fromarray(rgb).save(os.path.join(root, "JPEGImages", "480p", name, f"{t:05d}.jpg"), quality=95)
+            lab = np.zeros((H, W), np.uint8)
+            for o in range(k):
+                lab[msk[o, t] > 0.5] = o + 1
+            pim = Image.fromarray(lab, mode="P")
+            pim.putpalette([0, 0, 0, 255, 0, 0, 0, 255, 0, 0, 0, 255] + [0] * (256 * 3 - 12))
+            pim.save(os.path.join(root, "Annotations", "480p", name, f"{t:05d}.png"))
+        names.append(name)
+    os.makedirs(os.path.join(root, "ImageSets"), exist_ok=True)
+    imset = os.path.join(root, "ImageSets", "synthetic.txt")
+    open(imset, "w").write("\n".join(names) + "\n")
+    return imset
+
+
+# ------------------------------------------------------------------------------------------------ policy
+def per_frame_j(processor, gt_dev: torch.Tensor, interacted: List[int]) -> tuple:
+    """J per frame on the GPU.  Annotated frames count with their GT mask (interactions/eval.py:57-60);
+    frames without the object get the NO_OBJECT token.  Returns (quality[T], generated masks uint8 [T,H,W])."""
+    lw, uw, lh, uh = processor.pad
+    seg = processor.masks[:, 0, lh:processor.nh - uh, lw:processor.nw - uw] > 0
+    gtb = gt_dev > 0.5
+    gen = seg.clone()
+    if interacted:
+        gen[interacted] = gtb[interacted]
+    rows = metrics.sequence_scores_gpu(gtb, gen)
+    q = rows[:, 0].copy()
+    q[(gtb.flatten(1).sum(1) == 0).cpu().numpy()] = NO_OBJECT
+    return q, gen.to(torch.uint8)
+
+
+def oracle_rounds(processor, sample, rounds: int = 8):
+    """The oracle annotation policy of the FQ dataset (interactions/mask.py:113-156)."""
+    T = sample["num_frames"]
+    gt = sample["gt"][0].to(processor.prob.device)              # [T,1,H,W]
+    gt_thw = gt[:, 0]
+    frames, quality, states, gens = [0], None, [], []
+    for r in range(1, rounds + 1):
+        if r >= T:
+            continue
+        if quality is not None and not (set(range(T)) - set(np.where(quality == NO_OBJECT)[0].tolist()) - set(frames)):
+            continue
+        f = frames[r - 1]
+        processor.interact(gt[f][None], f)                         # [1,1,H,W] mask of the annotated frame
+        quality, gen = per_frame_j(processor, gt_thw, frames[:r])
+        worst = int(np.argmin(quality))
+        frames.append(worst)
+        states.append((worst, quality.copy()))
+        gens.append(gen)
+    return states, gens
+
+
+# ------------------------------------------------------------------------------------------------ output
+def save_state_masks(gen: torch.Tensor, out_dir: str):
+    """224x224 nearest-neighbour PNGs like util/fq_dataset.py:64-84 (mask_to_224)."""
+    os.makedirs(out_dir, exist_ok=True)
+    small = torch.nn.functional.interpolate(gen[:, None].float(), size=(224, 224), mode="nearest")[:, 0]
+    for t, m in enumerate((small * 255).to(torch.uint8).cpu().numpy()):
+        Image.fromarray(m).save(os.path.join(out_dir, f"{t:05d}.png"))
+
+
+def run(root: str, imset: str, out: str, prop_net, fuse_net, rounds: int = 8, save_masks: bool = True,
+        device: str = "cuda"):
+    """Process this rank's share of the samples; returns the gathered rows on every rank
+    (rows: sample id, round, selected frame, T, then T per-frame J values padded with NaN)."""
+    import torch.distributed as dist
+
+    from mivos.inference_core import InferenceCore
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    ds = ClipDataset(root, imset)
+    t_max = max(s[2] for s in ds.samples)
+    mine = sorted(shard.lpt_assign([s[2] for s in ds.samples], world)[rank])     # adjacent objects share a decode
+    width = 4 + t_max
+    rows = []
+    for i in mine:
+        sample = ds[i]
+        proc = InferenceCore(prop_net, fuse_net, sample["rgb"].to(device), 1)
+        states, gens = oracle_rounds(proc, sample, rounds)
+        sid = 1
+        for r, ((worst, q), gen) in enumerate(zip(states, gens)):
+            if float(q[worst]) == NO_OBJECT:
+                continue                                   # util/fq_dataset.py:55: no-object states are not saved
+            row = np.full(width, np.nan, np.float32)
+            row[:4] = (i, sid, worst, len(q))
+            row[4:4 + len(q)] = q
+            rows.append(row)
+            if save_masks:
+                save_state_masks(gen, os.path.join(out, "Annotations", "224", f"{sample['name']}_round_{sid}"))
+            sid += 1
+        del proc
+    allrows = shard.gather_rows(np.stack(rows) if rows else np.zeros((0, width), np.float32), width)
+    if rank == 0:
+        os.makedirs(out, exist_ok=True)
+        order = np.lexsort((allrows[:, 1], allrows[:, 0]))
+        with open(os.path.join(out, "res_fq.csv"), "w", newline="") as f:
+            wr = csv.writer(f)
+            wr.writerow(["state_name", "ious", "selected_frame"])
+            for row in allrows[order]:
+                n = int(row[3])
+                wr.writerow([f"{ds.name(int(row[0]))}_round_{int(row[1])}", [round(float(v), 6) for v in row[4:4 + n]],
+                             int(row[2])])
+    return allrows
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--root", required=True)
+    ap.add_argument("--imset", required=True)
+    ap.add_argument("--out", default="FQ_DB")
+    ap.add_argument("--prop-weights", default="./model_weights/mivos/stcn_yt_vos.pth")
+    ap.add_argument("--fusion-weights", default="./model_weights/mivos/fusion_stcn_yt_vos.pth")
+    ap.add_argument("--synthetic-weights", action="store_true", help="use the deterministic recipe (no checkpoints)")
+    ap.add_argument("--rounds", type=int, default=8)
+    a = ap.parse_args()
+    import torch.distributed as dist
+
+    from . import synth
+    from .params import FusionNet, PropagationNetwork
+    torch.set_grad_enabled(False)
+    if int(os.environ.get("WORLD_SIZE", 1)) > 1:
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
+        dist.init_process_group("nccl")
+    prop, fuse = PropagationNetwork(), FusionNet()
+    if a.synthetic_weights:
+        prop.load_state_dict(synth.recipe_state_dict(prop))
+        fuse.load_state_dict(synth.recipe_state_dict(fuse))
+    else:
+        prop.load_state_dict(torch.load(a.prop_weights, map_location="cpu"))
+        fuse.load_state_dict(torch.load(a.fusion_weights, map_location="cpu"))
+    rows = run(a.root, a.imset, a.out, prop.eval(), fuse.eval(), a.rounds)
+    if not dist.is_initialized() or dist.get_rank() == 0:
+        print(f"{len(rows)} states -> {os.path.join(a.out, 'res_fq.csv')}")
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -201,3 +201,36 @@ def test_edge_shapes_match_oracle(T, idx, k, mf, nets, weights):
     assert np.quantile(d, 0.999) < 3e-3
     s = core.stats()
     assert s["frames"] == T - 1 and s["fused"] == 0
+
+
+def test_fq_driver_end_to_end(nets, tmp_path):
+    """Config-4-shaped loop on a synthetic dataset tree: loader -> InferenceCore -> GPU J -> oracle policy
+    (8 rounds, worst frame next) -> 224x224 PNG states + CSV (reference generate_fq_dataset.py:60-86)."""
+    import csv
+    import os
+    from eva_vos_amd import fq_driver
+    imset = fq_driver.make_synthetic_tree(str(tmp_path / "db"), {"v0": (6, 112, 128, 2), "v1": (5, 112, 128, 1)})
+    out = str(tmp_path / "fq")
+    rows = fq_driver.run(str(tmp_path / "db"), imset, out, nets[0], nets[1], rounds=4)
+    assert rows.shape[1] == 4 + 6 and len(rows) > 0
+    for row in rows:
+        n, worst = int(row[3]), int(row[2])
+        q = row[4:4 + n]
+        assert np.all((q >= 0) & (q <= 1)) and np.isnan(row[4 + n:]).all()
+        assert worst == int(np.argmin(q)), "the next annotated frame is the worst one by J"
+    by_sample = {}
+    for row in rows:
+        by_sample.setdefault(int(row[0]), []).append(row)
+    assert set(by_sample) == {0, 1, 2}
+    for rs in by_sample.values():                       # annotated frames count with their GT: J == 1 there
+        assert rs[0][4] == 1.0
+        if len(rs) > 1:
+            assert rs[1][4 + int(rs[0][2])] == 1.0
+    with open(os.path.join(out, "res_fq.csv")) as f:
+        lines = list(csv.reader(f))
+    assert lines[0] == ["state_name", "ious", "selected_frame"] and len(lines) == 1 + len(rows)
+    assert lines[1][0] == "v0__1_round_1"
+    d = os.path.join(out, "Annotations", "224", "v0__1_round_1")
+    assert sorted(os.listdir(d)) == [f"{t:05d}.png" for t in range(6)]
+    from PIL import Image
+    assert Image.open(os.path.join(d, "00000.png")).size == (224, 224)

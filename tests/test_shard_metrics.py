@@ -72,3 +72,20 @@ def test_j_and_f_known_answers():
     assert b.sum() == 2 * 20 + 2 * 20 and b[9, 19] and not b[10, 20]                     # half-pixel offset to origin
     rows = metrics.sequence_scores(np.stack([gt, gt]), np.stack([gt, empty]))
     assert rows.shape == (2, 4) and rows[0, 3] == 1.0 and rows[1, 3] == 0.0
+
+
+def test_clip_dataset_layout_and_normalisation(tmp_path):
+    """CPU: the loader side of the FQ driver (reference datasets/annotation_dataset.py:80-132): one sample per
+    (video, object), ImageNet normalisation, GT without a background channel, decode cache per video."""
+    from eva_vos_amd import fq_driver
+    imset = fq_driver.make_synthetic_tree(str(tmp_path), {"vidA": (4, 48, 64, 2), "vidB": (3, 48, 64, 1)})
+    ds = fq_driver.ClipDataset(str(tmp_path), imset)
+    assert [ds.name(i) for i in range(len(ds))] == ["vidA__1", "vidA__2", "vidB__1"]
+    s0, s1, s2 = ds[0], ds[1], ds[2]
+    assert tuple(s0["rgb"].shape) == (1, 4, 3, 48, 64) and tuple(s0["gt"].shape) == (1, 4, 1, 48, 64)
+    assert s0["rgb"].data_ptr() == s1["rgb"].data_ptr(), "objects of one video share the decoded clip"
+    assert tuple(s2["rgb"].shape) == (1, 3, 3, 48, 64)
+    assert set(np.unique(s0["gt"].numpy())) <= {0.0, 1.0} and s0["gt"].sum() > 0 and s1["gt"].sum() > 0
+    assert float((s0["gt"] * s1["gt"]).sum()) == 0.0, "objects are disjoint"
+    px = s0["rgb"][0, 0, :, 5, 7].numpy() * fq_driver.STD + fq_driver.MEAN          # undo the normalisation
+    assert np.all(px >= -1e-6) and np.all(px <= 1 + 1e-6)
