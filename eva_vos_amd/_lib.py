@@ -46,6 +46,7 @@ PROTOTYPES = {
     "stcn_test_decode": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
     "stcn_test_attention": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "stcn_test_fusion": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _I, _I, _P]),
+    "stcn_debug_overlap": (_I, [_I, _I, _I, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "stcn_metrics_jf_counts": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
     "stcn_bench_conv": (_I, [_P] + [_I] * 11 + [C.POINTER(_F), C.POINTER(_D)]),
     "stcn_engine_set_profiling": (_I, [_P, _I]),

@@ -343,7 +343,7 @@ void conv_launch(const ConvP &p, hipStream_t s, hipEvent_t *ev_gemm, hipEvent_t 
     const dim3 grid(ntile * p.splitk);
     const bool smallc = (p.Cin % 32) != 0 || (p.x1 && (p.c0 % 32) != 0) || p.KH * p.KW > 32;
     hipEvent_t e0 = ev_gemm ? ev_gemm[0] : nullptr, e1 = ev_gemm ? ev_gemm[1] : nullptr;
-    if (p.mode == 1) {
+    if (p.mode & 1) {
         conv_f16x3_launch(p, tiles_n, ntile, per, grid, s, e0, e1);
     } else {
 #define STCN_LAUNCH(WM_, WN_, SC_, RL_)                                                                              \

@@ -158,7 +158,7 @@ static int add_convs(Model &m, const std::map<std::string, HostT> &sd) {
         if (rc) return rc;
         rc = upload(m, bias, &cw.bias);
         if (rc) return rc;
-        if (m.precision == 1 && cout > 1 && (rc = make_f16_split(m, cw, w))) return rc;
+        if ((m.precision & 1) && cout > 1 && (rc = make_f16_split(m, cw, w))) return rc;
         cw.bias0 = bias[0];
         m.conv[pre] = cw;
         // Convs over a channel concat [per-object part | frame-only part]: conv is linear in the input
@@ -183,7 +183,7 @@ static int add_convs(Model &m, const std::map<std::string, HostT> &sd) {
                                     wt.p[(((size_t)n * cin + c) * kh + y) * kw + x] * scale[n];
                 std::vector<float> bb = part ? bias : std::vector<float>(cout, 0.f);
                 if ((rc = upload(m, ww, &pw.w)) || (rc = upload(m, bb, &pw.bias))) return rc;
-                if (m.precision == 1 && (rc = make_f16_split(m, pw, ww))) return rc;
+                if ((m.precision & 1) && (rc = make_f16_split(m, pw, ww))) return rc;
                 pw.bias0 = bb[0];
                 m.conv[pre + (part ? "#b" : "#a")] = pw;
             }
@@ -308,7 +308,7 @@ int run_conv(const Model &m, Work &w, hipStream_t s, const char *name, const flo
     p.w_bytes = (unsigned)((long)cw.cout * cw.Kp * 4);
     if (x1 && ((cw.cin_p % 32) || (c0 % 32) || cw.kh * cw.kw > 32)) { set_error("conv '%s': two-source input needs 32-aligned channel splits", name); return STCN_E_INVALID; }
     p.w = cw.w; p.w_hi = cw.w_hi; p.w_lo = cw.w_lo; p.oscale = cw.oscale;
-    p.mode = (m.precision == 1 && cw.w_hi) ? 1 : 0;
+    p.mode = ((m.precision & 1) && cw.w_hi) ? m.precision : 0;    // bits >= 4: debug switches of the f16x3 kernel
     p.bias = cw.bias; p.res = res; p.res_bs = res_bs; p.y = y; p.y_bs = y_bs;
     p.relu_in = relu_in; p.relu_out = relu_out;
     p.splitk = force_splitk > 0 ? force_splitk : conv_choose_splitk(p);
@@ -595,9 +595,6 @@ static int engine_alloc_common(stcn_engine *e) {
     const char *la = getenv("STCN_LOOKAHEAD");
     e->lookahead = la ? atoi(la) : 2;
     if (e->T > e->n_slots) e->lookahead = 0;
-    // f16x3 mode is only validated for serial execution (run-to-run differences were observed
-    // when its kernels overlapped with the memory read on another stream)
-    if (e->model->precision == 1) e->lookahead = 0;
     if (e->lookahead > 0) {
         HIPCHK(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
         RC(e->work_side.init(d.nh, d.nw, 1));

@@ -106,4 +106,11 @@ void pack_fusion_input_launch(const float *img4, const float *prev, const float 
 void jf_counts_launch(const uint8_t *gt, const uint8_t *pred, int T, int H, int W, int radius, uint8_t *bmap,
                       int *counts, hipStream_t s);
 
+// debug/stress: launch ONLY the merge stage on prepared candidate lists (cand_v/cand_i [NC][Q][50])
+void merge_only_launch(const float *cand_v, const int32_t *cand_i, int NC, int Q, const float *mv, long mv_os, int k,
+                       float *readout, long ro_os, hipStream_t s);
+// debug/stress: trivial victim - out[q][c] = sum_j w[q][j] * table[idx[q][j]][c] with the same access pattern
+void gather_sum_launch(const float *table, const int32_t *idx, const float *w, int Q, float *out, hipStream_t s);
+void gather_sum_scalar_launch(const float *table, const int32_t *idx, const float *w, int Q, float *out, hipStream_t s);
+
 }  // namespace stcn

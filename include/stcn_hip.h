@@ -162,6 +162,11 @@ int stcn_get_kernel_flops(const stcn_engine *e, double *flops /*[STCN_K_COUNT]*/
 /* Algorithmic HBM bytes (every operand of every launch once; conv class only) of the last interact(). */
 int stcn_get_kernel_bytes(const stcn_engine *e, double *bytes /*[STCN_K_COUNT]*/);
 
+/* Debug stress test: victim kernel (0 = memory-read merge stage, 1 = plain gather-sum) on one stream, conv kernels
+ * (conv_mode 0 = fp32, 1 = f16x3, -1 = none) on another, `iters` overlapped repetitions; reports how many victim
+ * outputs differ from the solo result and the first differing element index. */
+int stcn_debug_overlap(int victim, int conv_mode, int iters, int *mismatching, int *first_bad_index);
+
 /* ---- caller-side metric -------------------------------------------------------
  * Integer counts behind J (region IoU) and F (boundary measure) for T frames, on the device.
  *   gt_dev, pred_dev : uint8 [T,H,W], non-zero = object (unpadded masks)
