@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--no-profile", action="store_true", help="skip the roofline leg (roofline = null)")
     ap.add_argument("--roof-steps", type=int, default=1, help="videos of the profiled single-stream roofline leg")
     ap.add_argument("--streams", type=int, default=3, help="videos in flight per GPU (one host thread + HIP stream each)")
+    ap.add_argument("--no-f16x3-leg", dest="f16x3_leg", action="store_false",
+                    help="skip the extra (non-headline) f16x3 split-precision leg")
     ap.add_argument("--r2", action="store_true", help="also time a second interaction (cached keys + fusion)")
     return ap.parse_args()
 
@@ -212,6 +214,29 @@ def main():
             del e
         os.environ["STCN_LOOKAHEAD"] = la_saved
 
+    # Extra leg (not the headline): the same timed region with the convs on the f16 MFMA pipe through the
+    # 3-term fp16 hi/lo operand split (fp32 accumulate, fp32-grade products; DESIGN.md "f16x3"), and how many
+    # mask pixels differ from the exact-fp32 run above.
+    extra = None
+    if a.f16x3_leg and world == 1 and os.environ.get("STCN_PRECISION") is None:
+        pool_main = pool
+        os.environ["STCN_PRECISION"] = "f16x3"
+        prop_main, prop = prop, PropagationNetwork()
+        prop.load_state_dict(psd)
+        pool = [[make(l) for _ in range(per_lane)] for l in range(S)]
+        run_all(mask0, 0)                                  # warm-up (one video per lane)
+        torch.cuda.synchronize()
+        tx = time.perf_counter()
+        resx = run_all(mask0, 0)
+        torch.cuda.synchronize()
+        dtx = time.perf_counter() - tx
+        extra = {"precision": "f16x3: fp16 hi/lo split operands, 3 x v_mfma_f32_32x32x16_f16 per K step, fp32 accumulate",
+                 "frames_per_s_rank0": sum(r[0] for r in resx) / dtx,
+                 "mask_pixels_differing_from_fp32_run": int((resx[0][1] != last).sum()),
+                 "mask_pixels_total": int(last.size)}
+        os.environ.pop("STCN_PRECISION")
+        pool, prop = pool_main, prop_main
+
     r2 = None
     if a.r2:
         torch.cuda.synchronize()
@@ -242,7 +267,8 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * dt_all / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if os.environ.get("STCN_PRECISION") != "f16x3" else "f16x3 (fp16 hi/lo split operands, f32 accumulate)",
+            "data": "synthetic",
             "config": {"workload": f"DAVIS-17-val-shaped {H}x{W} (padded {pool[0][0].nh}x{pool[0][0].nw}) {'single' if K_OBJ == 1 else K_OBJ}-object "
                                    f"STCN propagate: fresh engine, interact(mask,0), T={T} frames/video, "
                                    f"mem_freq={a.mem_freq}, top_k=50; one video per step per GPU",
@@ -255,6 +281,8 @@ def main():
         }
         if r2 is not None:
             out["r2_frames_per_s_rank0"] = r2
+        if extra is not None:
+            out["extra_f16x3_leg"] = extra
         if prof is not None:
             conv = prof["conv"]
             ach = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0

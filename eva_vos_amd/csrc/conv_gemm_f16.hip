@@ -30,42 +30,6 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 static constexpr int BK = 32;
 static constexpr int LDH = 40;                    // LDS row stride in halfs (80 B)
 static constexpr unsigned OOB = 0x80000000u;
-typedef float f32x4_ __attribute__((ext_vector_type(4)));
-typedef short short8 __attribute__((ext_vector_type(8)));
-// debug dispatcher for the overlap stress test: dbg bit0 = no MFMA, bit6 (64) = 4x 16x16x32 f16 instead (garbage
-// result, same pipe), bit7 (128) = 32x32x16 bf16 instead
-__device__ __forceinline__ f32x16 mma_dbg(int dbg, half8 a, half8 b, f32x16 c, int, int, int) {
-    if (dbg & 1) return c;
-    if (dbg & 64) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            f32x4_ t = {c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]};
-            t = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, t, 0, 0, 0);
-            c[4 * q] = t[0]; c[4 * q + 1] = t[1]; c[4 * q + 2] = t[2]; c[4 * q + 3] = t[3];
-        }
-        return c;
-    }
-    if (dbg & 128) {
-        typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), c, 0, 0, 0);
-    }
-    if (dbg & 256) {          // pad: idle issue slots after the MFMA
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-        asm volatile("s_nop 15\n\ts_nop 15" ::: );
-        return c;
-    }
-    if (dbg & 512) {          // accumulate in arch VGPRs instead of AGPRs
-        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
-        return c;
-    }
-    if (dbg & 1024) {         // lower MFMA issue priority relative to other waves
-        __builtin_amdgcn_s_setprio(0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-        return c;
-    }
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-}
-
 static constexpr float ASCALE = 4.f;              // activations are split as fp16(4 x): overflow only beyond |x| = 16376
 
 template <int WM, int WN, bool SMALLC, bool RELU>
@@ -85,7 +49,6 @@ __global__ __launch_bounds__(256) void conv_gemm_f16x3_kernel(const ConvP p, con
     const int tile = swz - split * ntile;
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
 
-    const int dbg = p.mode >> 4;   // debug switches (stress test): 1 no MFMA, 2 no LDS writes, 4 no weight loads, 8 no A loads, 16 no split math, 32 no stores
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / WN, wn = wave - wm * WN;
     const int kc = t & 7, r0 = t >> 3;            // A staging: row r0 (+32 i), 4-float chunk kc
@@ -173,17 +136,13 @@ __global__ __launch_bounds__(256) void conv_gemm_f16x3_kernel(const ConvP p, con
         } else {
             const bool ok = (vmask[i] >> g_bit) & 1u;
             voff = ok ? (unsigned)((g_src1 ? roff1[i] : roff0[i]) + g_coff) : OOB;
-            if (dbg & 8) ra[ST][i] = f32x4{1.f, 2.f, 3.f, 4.f};
-            else ra[ST][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_src1 ? rs1 : rs0, voff, 0, 0));
+            ra[ST][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_src1 ? rs1 : rs0, voff, 0, 0));
         }
     };
     auto g_b = [&](int kt, auto setc) {
         constexpr int ST = decltype(setc)::value;
-        if (dbg & 4) { rbh[ST] = u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u}; rbl[ST] = u32x4{0u, 0u, 0u, 0u}; }
-        else {
-            rbh[ST] = __builtin_amdgcn_raw_buffer_load_b128(rwh, woff, kt * (BK * 2), 0);
-            rbl[ST] = __builtin_amdgcn_raw_buffer_load_b128(rwl, woff, kt * (BK * 2), 0);
-        }
+        rbh[ST] = __builtin_amdgcn_raw_buffer_load_b128(rwh, woff, kt * (BK * 2), 0);
+        rbl[ST] = __builtin_amdgcn_raw_buffer_load_b128(rwl, woff, kt * (BK * 2), 0);
     };
     _Float16 *const a_st = Ah + r0 * LDH + kc * 4;
     _Float16 *const b_st = Bh + br * LDH + bc * 8;
@@ -194,16 +153,13 @@ __global__ __launch_bounds__(256) void conv_gemm_f16x3_kernel(const ConvP p, con
         v = v * ASCALE;
         half4 hi = __builtin_convertvector(v, half4);
         half4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), half4);
-        if (dbg & 16) { hi = half4{1, 1, 1, 1}; lo = half4{0, 0, 0, 0}; }
         _Float16 *dst = a_st + buf * BUF + 32 * i * LDH;
-        if (!(dbg & 2)) {
-            *reinterpret_cast<half4 *>(dst) = hi;
-            *reinterpret_cast<half4 *>(dst + BM * LDH) = lo;
-        }
+        *reinterpret_cast<half4 *>(dst) = hi;
+        *reinterpret_cast<half4 *>(dst + BM * LDH) = lo;
     };
     auto s_b = [&](int buf, auto setc) {
         constexpr int ST = decltype(setc)::value;
-        if (bact && !(dbg & 2)) {
+        if (bact) {
             *reinterpret_cast<u32x4 *>(b_st + buf * BUF) = rbh[ST];
             *reinterpret_cast<u32x4 *>(b_st + buf * BUF + BN * LDH) = rbl[ST];
         }
@@ -251,22 +207,22 @@ __global__ __launch_bounds__(256) void conv_gemm_f16x3_kernel(const ConvP p, con
             fbl[ks] = *reinterpret_cast<const half8 *>(bl + 16 * ks);
         }
         // staging for the following tiles is issued between the MFMAs (same scheme as the fp32 kernel)
-        acc = mma_dbg(dbg, fah[0], fbh[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[0], fbh[0], acc, 0, 0, 0);
         g_tap(kt2);
         __builtin_amdgcn_sched_barrier(0);
-        acc = mma_dbg(dbg, fah[1], fbh[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[1], fbh[1], acc, 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < WM; ++i) g_a(i, gsc);
         g_b(kt2c, gsc);
         __builtin_amdgcn_sched_barrier(0);
-        acc = mma_dbg(dbg, fah[0], fbl[0], acc, 0, 0, 0);
-        acc = mma_dbg(dbg, fah[1], fbl[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[0], fbl[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[1], fbl[1], acc, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        acc = mma_dbg(dbg, fal[0], fbh[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[0], fbh[0], acc, 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < WM; ++i) s_a(i, buf ^ 1, SS{});
         __builtin_amdgcn_sched_barrier(0);
-        acc = mma_dbg(dbg, fal[1], fbh[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[1], fbh[1], acc, 0, 0, 0);
         s_b(buf ^ 1, SS{});
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
@@ -280,7 +236,7 @@ __global__ __launch_bounds__(256) void conv_gemm_f16x3_kernel(const ConvP p, con
 
     // ---- epilogue: undo the power-of-two operand scaling, then bias / residual / ReLU (fp32)
     const int n = tn * BN + wn * 32 + (lane & 31);
-    if (n >= p.N || (dbg & 32)) return;
+    if (n >= p.N) return;
     const float osc = p.oscale[n];
     const int mbase = tm * BM + wm * 32 + 4 * (lane >> 5);
     if (p.splitk > 1) {

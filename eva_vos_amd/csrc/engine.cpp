@@ -308,7 +308,7 @@ int run_conv(const Model &m, Work &w, hipStream_t s, const char *name, const flo
     p.w_bytes = (unsigned)((long)cw.cout * cw.Kp * 4);
     if (x1 && ((cw.cin_p % 32) || (c0 % 32) || cw.kh * cw.kw > 32)) { set_error("conv '%s': two-source input needs 32-aligned channel splits", name); return STCN_E_INVALID; }
     p.w = cw.w; p.w_hi = cw.w_hi; p.w_lo = cw.w_lo; p.oscale = cw.oscale;
-    p.mode = ((m.precision & 1) && cw.w_hi) ? m.precision : 0;    // bits >= 4: debug switches of the f16x3 kernel
+    p.mode = ((m.precision & 1) && cw.w_hi) ? 1 : 0;
     p.bias = cw.bias; p.res = res; p.res_bs = res_bs; p.y = y; p.y_bs = y_bs;
     p.relu_in = relu_in; p.relu_out = relu_out;
     p.splitk = force_splitk > 0 ? force_splitk : conv_choose_splitk(p);

@@ -15,7 +15,7 @@ iters = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 FLAGS = {}
 modes = [(-1, "no conv"), (0, "fp32 conv"), (1, "f16x3 conv")]
 modes += [(1 | (f << 4), "f16x3 " + n) for f, n in FLAGS.items()]
-for victim, vname in ((1, "gather_sum (v_pk_fma)"), (2, "gather_sum (v_fmac)")):
+for victim, vname in ((1, "gather_sum (float2 fma)"), (2, "gather_sum (v_fmac)")):
     for mode, mname in modes:
         bad, first = C.c_int(), C.c_int()
         _lib.check(lib.stcn_debug_overlap(victim, mode, iters, C.byref(bad), C.byref(first)))
