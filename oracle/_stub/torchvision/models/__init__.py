@@ -52,3 +52,49 @@ class _R50(nn.Module):
 
 def resnet50(weights=None, **kw):
     return _R50()
+
+
+# ---- ResNet-18 (BasicBlock) for the reference QualityNet (models/modules.py:12-62); the other names that file
+# imports are never constructed by the goldens
+class BasicBlock(nn.Module):
+    def __init__(self, cin, planes, stride=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = None
+        if stride != 1 or cin != planes:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, planes, 1, stride, bias=False), nn.BatchNorm2d(planes))
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        y = self.relu(self.bn1(self.conv1(x)))
+        y = self.bn2(self.conv2(y))
+        return self.relu(y + idt)
+
+
+class _R18(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        self.layer1 = nn.Sequential(BasicBlock(64, 64), BasicBlock(64, 64))
+        self.layer2 = nn.Sequential(BasicBlock(64, 128, 2), BasicBlock(128, 128))
+        self.layer3 = nn.Sequential(BasicBlock(128, 256, 2), BasicBlock(256, 256))
+        self.layer4 = nn.Sequential(BasicBlock(256, 512, 2), BasicBlock(512, 512))
+
+
+def resnet18(weights=None, **kw):
+    return _R18()
+
+
+def _absent(*a, **k):
+    raise NotImplementedError("not part of the stub")
+
+
+resnet101 = vit_b_16 = vit_b_32 = vit_l_32 = _absent
+ResNet18_Weights = ResNet101_Weights = ViT_B_16_Weights = ViT_B_32_Weights = ViT_L_32_Weights = ResNet50_Weights
