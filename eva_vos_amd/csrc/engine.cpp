@@ -251,7 +251,7 @@ static int build_model(Model &m, const stcn_weight_desc *prop, int n_prop, const
 }
 
 // ---------------------------------------------------------------------------------------------- Work
-int Work::init(int nh, int nw, int k_) {
+int Work::init(int nh, int nw, int k_, int key_batch) {
     d.set(nh, nw);
     k = k_;
     auto alloc = [&](void **p, size_t bytes) -> int {
@@ -260,8 +260,10 @@ int Work::init(int nh, int nw, int k_) {
         return STCN_OK;
     };
     const size_t s1 = (size_t)k * d.hw2 * 64, s2 = (size_t)d.npix * 32, s3 = (size_t)k * d.hw4 * 256;
+    const size_t s4 = (size_t)key_batch * d.hw2 * 64;          // batched key encoder
     S = s1 > s2 ? s1 : s2;
     S = S > s3 ? S : s3;
+    S = S > s4 ? S : s4;
     int rc;
     for (float **b : {&A, &B, &C, &D})
         if ((rc = alloc((void **)b, S * sizeof(float)))) return rc;
@@ -338,14 +340,25 @@ static int conv1(const Model &m, Work &w, hipStream_t s, const std::string &name
                     (long)OH * OW * cw.cout, relu_in, relu_out);
 }
 
-// KeyEncoder (modules.py:127-149) + key_proj/key_comp (prop_net.py:172-177) + decoder skip convs
-int encode_key(const Model &m, Work &w, hipStream_t s, const float *img4, const KeyOut &o) {
+// KeyEncoder (modules.py:127-149) + key_proj/key_comp (prop_net.py:172-177) + decoder skip convs, for B frames at
+// once: images are B consecutive frames of the packed clip, the outputs of frame b land at o.<ptr> + b * out_bs
+// (consecutive key-cache slots).  Batching only changes M of every implicit GEMM (B x more rows per launch).
+int encode_key(const Model &m, Work &w, hipStream_t s, const float *img4, const KeyOut &o, int B, long out_bs) {
     const Dims &d = w.d;
-    RC(conv1(m, w, s, "key_encoder.conv1", img4, 4, 1, d.nh, d.nw, 2, w.A, nullptr, 0, 1));
-    { Scope sc(w.prof, STCN_K_ELEMWISE, s); maxpool3x3s2_launch(w.A, w.B, 1, d.h2, d.w2, 64, s); }
+    // conv with explicit batch strides on input / output / residual (0 = densely packed [B][H][W][C])
+    auto cv = [&](const std::string &name, const float *x, int cin, long x_bs, int H, int W, int stride, float *y,
+                  long y_bs, const float *res, long res_bs, int relu_in, int relu_out) -> int {
+        const ConvW &cw = m.c(name);
+        const int OH = (H + 2 * (cw.kh / 2) - cw.kh) / stride + 1, OW = (W + 2 * (cw.kw / 2) - cw.kw) / stride + 1;
+        return run_conv(m, w, s, name.c_str(), x, cin, x_bs ? x_bs : (long)H * W * cin, nullptr, 0, 0, B, H, W, stride, y,
+                        B > 1 ? y_bs : 0, res, res_bs ? res_bs : (long)OH * OW * cw.cout, relu_in, relu_out);
+    };
+    RC(cv("key_encoder.conv1", img4, 4, 0, d.nh, d.nw, 2, w.A, 0, nullptr, 0, 0, 1));
+    { Scope sc(w.prof, STCN_K_ELEMWISE, s); maxpool3x3s2_launch(w.A, w.B, B, d.h2, d.w2, 64, s); }
     struct St { const char *name; int n, planes, stride; } stages[3] = {{"res2", 3, 64, 1}, {"layer2", 4, 128, 2}, {"layer3", 6, 256, 2}};
     int H = d.h4, W = d.w4, cin = 64;
     float *x = w.B;
+    long x_bs = 0;
     for (int si = 0; si < 3; ++si) {
         const St &st = stages[si];
         for (int i = 0; i < st.n; ++i) {
@@ -353,30 +366,36 @@ int encode_key(const Model &m, Work &w, hipStream_t s, const float *img4, const 
             const int sd = i == 0 ? st.stride : 1;
             const int OH = H / sd, OW = W / sd;
             const float *idt = x;
-            if (i == 0) { RC(conv1(m, w, s, p + ".downsample.0", x, cin, 1, H, W, sd, w.D, nullptr, 0, 0)); idt = w.D; }
-            RC(conv1(m, w, s, p + ".conv1", x, cin, 1, H, W, 1, w.C, nullptr, 0, 1));
-            RC(conv1(m, w, s, p + ".conv2", w.C, st.planes, 1, H, W, sd, w.A, nullptr, 0, 1));
+            if (i == 0) { RC(cv(p + ".downsample.0", x, cin, 0, H, W, sd, w.D, 0, nullptr, 0, 0, 0)); idt = w.D; }
+            RC(cv(p + ".conv1", x, cin, 0, H, W, 1, w.C, 0, nullptr, 0, 0, 1));
+            RC(cv(p + ".conv2", w.C, st.planes, 0, H, W, sd, w.A, 0, nullptr, 0, 0, 1));
             float *dst = x;
-            if (si == 2 && i == st.n - 1) dst = o.f16;
-            RC(conv1(m, w, s, p + ".conv3", w.A, st.planes, 1, OH, OW, 1, dst, idt, 0, 1));
-            x = dst; H = OH; W = OW; cin = st.planes * 4;
+            long dst_bs = 0;
+            if (si == 2 && i == st.n - 1) { dst = o.f16; dst_bs = out_bs; }
+            RC(cv(p + ".conv3", w.A, st.planes, 0, OH, OW, 1, dst, dst_bs, idt, 0, 0, 1));
+            x = dst; x_bs = dst_bs; H = OH; W = OW; cin = st.planes * 4;
         }
         if (si == 0) {
             if (o.f4_copy) HIPCHK(hipMemcpyAsync(o.f4_copy, x, (size_t)d.hw4 * 256 * 4, hipMemcpyDeviceToDevice, s));
-            if (o.s4) RC(conv1(m, w, s, "decoder.up_8_4.skip_conv", x, 256, 1, d.h4, d.w4, 1, o.s4, nullptr, 0, 0));
+            if (o.s4) RC(cv("decoder.up_8_4.skip_conv", x, 256, 0, d.h4, d.w4, 1, o.s4, out_bs, nullptr, 0, 0, 0));
         } else if (si == 1) {
             if (o.f8_copy) HIPCHK(hipMemcpyAsync(o.f8_copy, x, (size_t)d.hw8 * 512 * 4, hipMemcpyDeviceToDevice, s));
-            if (o.s8) RC(conv1(m, w, s, "decoder.up_16_8.skip_conv", x, 512, 1, d.h8, d.w8, 1, o.s8, nullptr, 0, 0));
+            if (o.s8) RC(cv("decoder.up_16_8.skip_conv", x, 512, 0, d.h8, d.w8, 1, o.s8, out_bs, nullptr, 0, 0, 0));
         }
     }
+    const long f16_bs = B > 1 ? x_bs : 0;           // o.f16 of consecutive slots
     if (o.k16) {
-        RC(conv1(m, w, s, "key_proj.key_proj", o.f16, 1024, 1, d.h16, d.w16, 1, o.k16, nullptr, 0, 0));
-        if (o.msq) { Scope sc(w.prof, STCN_K_ELEMWISE, s); rowsumsq_launch(o.k16, d.hw16, 64, o.msq, s); }
+        RC(cv("key_proj.key_proj", o.f16, 1024, f16_bs, d.h16, d.w16, 1, o.k16, out_bs, nullptr, 0, 0, 0));
+        if (o.msq) {
+            Scope sc(w.prof, STCN_K_ELEMWISE, s);
+            for (int b = 0; b < B; ++b) rowsumsq_launch(o.k16 + b * out_bs, d.hw16, 64, o.msq + b * out_bs, s);
+        }
     }
-    if (o.f16_thin) RC(conv1(m, w, s, "key_comp", o.f16, 1024, 1, d.h16, d.w16, 1, o.f16_thin, nullptr, 0, 0));
+    if (o.f16_thin) RC(cv("key_comp", o.f16, 1024, f16_bs, d.h16, d.w16, 1, o.f16_thin, out_bs, nullptr, 0, 0, 0));
     if (o.f16_thin && o.dthin) {   // frame-only halves of decoder.compress (see add_convs)
-        RC(conv1(m, w, s, "decoder.compress.downsample#b", o.f16_thin, 512, 1, d.h16, d.w16, 1, o.dthin, nullptr, 0, 0));
-        RC(conv1(m, w, s, "decoder.compress.conv1#b", o.f16_thin, 512, 1, d.h16, d.w16, 1, o.cthin, nullptr, 1, 0));
+        const long t_bs = B > 1 ? out_bs : 0;
+        RC(cv("decoder.compress.downsample#b", o.f16_thin, 512, t_bs, d.h16, d.w16, 1, o.dthin, out_bs, nullptr, 0, 0, 0));
+        RC(cv("decoder.compress.conv1#b", o.f16_thin, 512, t_bs, d.h16, d.w16, 1, o.cthin, out_bs, nullptr, 0, 1, 0));
     }
     return STCN_OK;
 }
@@ -588,16 +607,20 @@ static int engine_alloc_common(stcn_engine *e) {
     RC(eng_alloc(e, (void **)&e->mask_pad, (size_t)(e->k + 1) * d.npix * 4));
     RC(eng_alloc(e, (void **)&e->pos, (size_t)(e->k + 1) * d.npix * 4));
     RC(eng_alloc(e, (void **)&e->neg, (size_t)(e->k + 1) * d.npix * 4));
-    RC(e->work.init(d.nh, d.nw, e->k));
-    e->work.prof = &e->prof;
-    // Look-ahead is only used when no cache slot is ever recycled (T <= slots): the key encoder of the
-    // next frames then runs on a side stream concurrently with the memory-read / decoder chain.
     const char *la = getenv("STCN_LOOKAHEAD");
     e->lookahead = la ? atoi(la) : 2;
     if (e->T > e->n_slots) e->lookahead = 0;
+    const char *kb = getenv("STCN_KEY_BATCH");
+    e->key_batch = kb ? atoi(kb) : 4;
+    if (e->key_batch < 1) e->key_batch = 1;
+    if (e->key_batch > 8) e->key_batch = 8;
+    RC(e->work.init(d.nh, d.nw, e->k, e->lookahead > 0 ? 1 : e->key_batch));
+    e->work.prof = &e->prof;
+    // Look-ahead is only used when no cache slot is ever recycled (T <= slots): the key encoder of the
+    // next frames then runs on a side stream concurrently with the memory-read / decoder chain.
     if (e->lookahead > 0) {
         HIPCHK(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
-        RC(e->work_side.init(d.nh, d.nw, 1));
+        RC(e->work_side.init(d.nh, d.nw, 1, e->key_batch));
         e->work_side.prof = &e->prof;
         e->key_ready.assign(e->T, nullptr);
         for (int t = 0; t < e->T; ++t) HIPCHK(hipEventCreateWithFlags(&e->key_ready[t], hipEventDisableTiming));
@@ -707,27 +730,39 @@ int stcn_engine_clone(const stcn_engine *src, float *prob_dev, uint8_t *masks_de
 // key features of frame ti (cached; inference_core.py:115-124).  enqueue_key() starts the encoder for
 // a missing frame (on the side stream when look-ahead is on); ensure_key() additionally orders the main
 // stream behind it.
-static int enqueue_key(stcn_engine *e, int ti) {
+static int enqueue_key(stcn_engine *e, int ti, int step = 0, int stop = 0) {
     if (e->slot_of[ti] >= 0) return STCN_OK;
     if (e->n_cached >= e->n_slots) {                         // flush-all policy of the reference
         std::fill(e->slot_of.begin(), e->slot_of.end(), -1);
         std::fill(e->vparts_ready.begin(), e->vparts_ready.end(), 0);
         e->n_cached = 0;
     }
-    const int slot = e->n_cached++;
-    e->slot_of[ti] = slot;
-    e->vparts_ready[ti] = 0;
+    // one encoder pass covers ti and the following uncached frames of the sweep (direction `step`, up to but not
+    // including `stop`), into consecutive cache slots
+    int B = 1;
+    if (step != 0)
+        while (B < e->key_batch && e->n_cached + B < e->n_slots) {
+            const int tn = ti + B * step;
+            if (tn == stop || tn < 0 || tn >= e->T || e->slot_of[tn] >= 0) break;
+            ++B;
+        }
+    const int t_lo = step < 0 ? ti - (B - 1) : ti;           // batch element b = frame t_lo + b (ascending in memory)
+    const int slot = e->n_cached;
+    e->n_cached += B;
+    for (int b = 0; b < B; ++b) { e->slot_of[t_lo + b] = slot + b; e->vparts_ready[t_lo + b] = 0; }
     const SlotPtrs p = slot_ptrs(e, slot);
     KeyOut ko{p.k16, p.msq, p.f16_thin, p.f16, p.s8, p.s4, nullptr, nullptr, p.dthin, p.cthin};
-    const float *img = e->images4 + (size_t)ti * e->d.npix * 4;
+    const float *img = e->images4 + (size_t)t_lo * e->d.npix * 4;
     if (e->lookahead > 0) {
-        RC(encode_key(*e->model, e->work_side, e->side, img, ko));
-        HIPCHK(hipEventRecord(e->key_ready[ti], e->side));
-        e->key_pending[ti] = 1;
+        RC(encode_key(*e->model, e->work_side, e->side, img, ko, B, (long)e->slot_floats));
+        for (int b = 0; b < B; ++b) {
+            HIPCHK(hipEventRecord(e->key_ready[t_lo + b], e->side));
+            e->key_pending[t_lo + b] = 1;
+        }
     } else {
-        RC(encode_key(*e->model, e->work, e->stream, img, ko));
+        RC(encode_key(*e->model, e->work, e->stream, img, ko, B, (long)e->slot_floats));
     }
-    e->stats.key_miss++;
+    e->stats.key_miss += B;
     return STCN_OK;
 }
 
@@ -795,8 +830,8 @@ static int do_pass(stcn_engine *e, int idx, bool forward) {
     const long prs = (long)T * d.npix;                      // prob row stride
     Work &w = e->work;
     for (int ti = idx + step; ti != closest; ti += step) {
-        RC(enqueue_key(e, ti));
-        for (int a = 1, tj = ti + step; a <= e->lookahead && tj != closest; ++a, tj += step) RC(enqueue_key(e, tj));
+        RC(enqueue_key(e, ti, step, closest));
+        for (int a = 1, tj = ti + step; a <= e->lookahead && tj != closest; ++a, tj += step) RC(enqueue_key(e, tj, step, closest));
         SlotPtrs kf;
         RC(ensure_key(e, ti, &kf));
         {

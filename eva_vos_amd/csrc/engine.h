@@ -92,7 +92,7 @@ struct Work {
     float *vin = nullptr;               // value-encoder packed input [k][npix][8]
     Prof *prof = nullptr;
     std::vector<void *> allocs;
-    int init(int nh, int nw, int k);
+    int init(int nh, int nw, int k, int key_batch = 1);
     void release();
 };
 
@@ -101,7 +101,8 @@ struct KeyOut { float *k16, *msq, *f16_thin, *f16, *s8, *s4, *f8_copy, *f4_copy,
 int run_conv(const Model &m, Work &w, hipStream_t s, const char *name, const float *x0, int c0, long bs0,
              const float *x1, int c1, long bs1, int B, int H, int W, int stride, float *y, long y_bs,
              const float *res, long res_bs, int relu_in, int relu_out, int force_splitk = 0);
-int encode_key(const Model &m, Work &w, hipStream_t s, const float *img4, const KeyOut &o);
+// B consecutive frames at once; outputs of frame b at o.<ptr> + b * out_bs
+int encode_key(const Model &m, Work &w, hipStream_t s, const float *img4, const KeyOut &o, int B = 1, long out_bs = 0);
 // vd / vc: cached frame-only halves of fuser.block1 (nullptr: compute the full two-source convs)
 int encode_value(const Model &m, Work &w, hipStream_t s, const float *img4, const float *f16,
                  const float *masks, long mask_stride, float *out, long out_bs, const float *vd = nullptr,
@@ -145,6 +146,7 @@ struct stcn_engine {
     std::vector<hipEvent_t> key_ready;   // per frame: recorded on `side` after its encode_key
     std::vector<char> key_pending;       // per frame: main stream has not yet waited on key_ready
     int lookahead = 0;
+    int key_batch = 1;                   // frames per key-encoder pass (env STCN_KEY_BATCH)
     stcn::Prof prof;
     stcn_stats stats{};
     std::vector<void *> allocs;

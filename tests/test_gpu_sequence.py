@@ -167,6 +167,29 @@ def test_long_clip_exercises_cache_flush_policy(nets, weights):
     assert np.quantile(d, 0.999) < 3e-3
 
 
+@pytest.mark.parametrize("lookahead", ["0", "2"])
+def test_key_batching_does_not_change_results(nets, monkeypatch, lookahead):
+    """The key encoder runs over up to STCN_KEY_BATCH frames per pass (forward sweeps ascending, backward sweeps
+    descending, stopping at interacted frames); per-frame results only see a different M of the same GEMMs."""
+    T, H, W = 15, 112, 144
+    img = synth.synthetic_clip(T, H, W, seed=4)
+    msk = synth.synthetic_mask(T, H, W, 1, seed=5)
+    monkeypatch.setenv("STCN_LOOKAHEAD", lookahead)
+    res = {}
+    for kb in ("1", "3", "4", "8"):
+        monkeypatch.setenv("STCN_KEY_BATCH", kb)
+        core = make_core(nets)(img, 1, 3)
+        m1 = core.interact(msk[:, 9], 9).copy()            # backward sweep 8..0 and forward sweep 10..14
+        s = core.stats()
+        assert s["key_miss"] == T and s["frames"] == T - 1
+        m2 = core.interact(msk[:, 4], 4).copy()            # all keys cached, fusion between 4 and 9
+        assert core.stats()["key_miss"] == 0
+        res[kb] = (m1, m2, core.prob.clone())
+    for kb in ("3", "4", "8"):
+        assert iou(res[kb][0], res["1"][0]) >= 1 - 1e-3 and iou(res[kb][1], res["1"][1]) >= 1 - 1e-3
+        assert (res[kb][2] - res["1"][2]).abs().max().item() < 2e-3
+
+
 def test_reset_equals_fresh_engine(nets):
     T, H, W = 6, 112, 144
     img, msk = synth.synthetic_clip(T, H, W), synth.synthetic_mask(T, H, W, 1)
