@@ -30,7 +30,7 @@ import numpy as np
 import torch
 
 from . import metrics, shard
-from .fq_driver import NO_OBJECT, ClipDataset
+from .fq_driver import NO_OBJECT, ClipDataset, prefetched
 
 POLICIES = ("oracle_mask", "rand_mask", "qnet_mask", "upper_bound_mask")
 MASK_SECONDS, SKIP_SECONDS = 80, 3            # annotation cost model of interactions/mask.py:33-36
@@ -124,9 +124,8 @@ def run(root: str, imset: str, out_csv: str, prop_net, fuse_net, policy: str = "
     mine = sorted(shard.lpt_assign([s[2] for s in ds.samples], world)[rank])
     width = 6 + t_max
     rows = []
-    for i in mine:
-        sample = ds[i]
-        proc = InferenceCore(prop_net, fuse_net, sample["rgb"].to(device), 1)
+    for i, sample in prefetched(ds, mine, device):
+        proc = InferenceCore(prop_net, fuse_net, sample["rgb"], 1)
         res = run_policy(policy, proc, sample, rounds, metric, qnet, random.Random(seed * 100003 + i))
         for r, (mu, sec, q) in enumerate(zip(res["mu_metrics"], res["annotation_times"], res["round_metrics"])):
             row = np.full(width, np.nan, np.float32)

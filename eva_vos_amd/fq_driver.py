@@ -67,7 +67,10 @@ class ClipDataset:
             lab = np.stack([np.array(Image.open(os.path.join(self.mask_dir, video, f"{f:05d}.png")).convert("P"),
                                      dtype=np.uint8) for f in range(n)])
             rgb = ((rgb - MEAN) / STD).transpose(0, 3, 1, 2)
-            self._cache[video] = (torch.from_numpy(np.ascontiguousarray(rgb)), torch.from_numpy(lab))
+            rgb = torch.from_numpy(np.ascontiguousarray(rgb))
+            if torch.cuda.is_available():
+                rgb = rgb.pin_memory()           # decoded once per video, uploaded asynchronously per sample
+            self._cache[video] = (rgb, torch.from_numpy(lab))
         return self._cache[video]
 
     def __getitem__(self, i):
@@ -75,6 +78,38 @@ class ClipDataset:
         rgb, lab = self._clip(v, n)
         gt = (lab == obj).float()[None, :, None]              # [1,T,1,H,W], no bg channel (reference layout)
         return {"rgb": rgb[None], "gt": gt, "name": self.name(i), "video": v, "num_frames": n}
+
+
+def prefetched(ds: "ClipDataset", indices, device: str = "cuda"):
+    """Yield (i, sample) for i in indices with sample['rgb'] already on `device`.  The NEXT sample is decoded on a
+    host thread (PIL releases the GIL) into pinned memory and copied H2D on a side stream while the caller propagates
+    the current one - the reference decodes and uploads synchronously between samples (generate_fq_dataset.py:60-63)."""
+    from concurrent.futures import ThreadPoolExecutor
+    on_gpu = torch.cuda.is_available() and str(device).startswith("cuda")
+    side = torch.cuda.Stream() if on_gpu else None
+
+    def load(i):
+        sample = dict(ds[i])
+        if on_gpu:
+            host = sample["rgb"].pin_memory()
+            with torch.cuda.stream(side):
+                sample["rgb"] = host.to(device, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            sample["_ready"], sample["_host"] = ev, host          # keep the pinned buffer alive until the copy is done
+        return sample
+
+    indices = list(indices)
+    with ThreadPoolExecutor(1) as pool:
+        fut = pool.submit(load, indices[0]) if indices else None
+        for n, i in enumerate(indices):
+            sample = fut.result()
+            fut = pool.submit(load, indices[n + 1]) if n + 1 < len(indices) else None
+            if on_gpu:
+                torch.cuda.current_stream().wait_event(sample.pop("_ready"))
+                sample["rgb"].record_stream(torch.cuda.current_stream())
+                sample.pop("_host")
+            yield i, sample
 
 
 def make_synthetic_tree(root: str, videos: Dict[str, tuple], seed: int = 0) -> str:
@@ -162,9 +197,8 @@ def run(root: str, imset: str, out: str, prop_net, fuse_net, rounds: int = 8, sa
     mine = sorted(shard.lpt_assign([s[2] for s in ds.samples], world)[rank])     # adjacent objects share a decode
     width = 4 + t_max
     rows = []
-    for i in mine:
-        sample = ds[i]
-        proc = InferenceCore(prop_net, fuse_net, sample["rgb"].to(device), 1)
+    for i, sample in prefetched(ds, mine, device):
+        proc = InferenceCore(prop_net, fuse_net, sample["rgb"], 1)
         states, gens = oracle_rounds(proc, sample, rounds)
         sid = 1
         for r, ((worst, q), gen) in enumerate(zip(states, gens)):
