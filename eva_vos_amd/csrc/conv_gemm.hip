@@ -38,10 +38,12 @@ static constexpr int LDT = 36;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 static constexpr unsigned OOB = 0x80000000u;    // byte offset beyond any tensor: buffer loads return 0
 
-template <int WM, int WN, bool SMALLC, bool RELU>
+// WM x WN waves per workgroup, each owning RM x RN accumulator blocks of 32x32: workgroup tile (32 WM RM) x (32 WN RN).
+template <int WM, int WN, int RM, int RN, bool SMALLC, bool RELU>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvP p, const int tiles_n,
                                                         const int ntile, const int kt_per_split) {
-    constexpr int BM = 32 * WM, BN = 32 * WN;
+    constexpr int PA = WM * RM, PB = WN * RN;          // 32-row pieces of the A / B tiles (= staging chunks per thread)
+    constexpr int BM = 32 * PA, BN = 32 * PB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *As = smem;                  // [2][BM][LDT]
     float *Bs = smem + 2 * BM * LDT;   // [2][BN][LDT]
@@ -66,12 +68,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvP p, const int
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w), 0, p.w_bytes, 0x00020000);
 
     // ---- per-thread im2col row state (rows r0 + 32*i of the A tile)
-    int ih0[WM], iw0[WM], roff0[WM], roff1[WM];      // roffX: byte offset of (b, ih0, iw0, channel kc*4) in source X
-    unsigned vmask[WM];                               // fast path: bit (kh*KW+kw) = tap inside the image
-    bool rvalid[WM];
+    int ih0[PA], iw0[PA], roff0[PA], roff1[PA];      // roffX: byte offset of (b, ih0, iw0, channel kc*4) in source X
+    unsigned vmask[PA];                               // fast path: bit (kh*KW+kw) = tap inside the image
+    bool rvalid[PA];
     const int ohw = p.OH * p.OW;
 #pragma unroll
-    for (int i = 0; i < WM; ++i) {
+    for (int i = 0; i < PA; ++i) {
         const int m = tm * BM + r0 + 32 * i;
         rvalid[i] = m < p.M;
         const int mm = rvalid[i] ? m : 0;
@@ -91,9 +93,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvP p, const int
         }
         vmask[i] = vm;
     }
-    unsigned woff[WN];                                // byte offset of weight row n, chunk kc (OOB when n >= N)
+    unsigned woff[PB];                                // byte offset of weight row n, chunk kc (OOB when n >= N)
 #pragma unroll
-    for (int i = 0; i < WN; ++i) {
+    for (int i = 0; i < PB; ++i) {
         const int n = tn * BN + r0 + 32 * i;
         woff[i] = n < p.N ? (unsigned)((n * p.Kp + kc * 4) * 4) : OOB;
     }
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvP p, const int
     //     S(t+1): staging registers -> the other LDS buffer (after the later MFMAs).
     //   Two staging register sets (tile parity) give every load ~1.5 iterations to land before its
     //   write-back; sched_barrier pins the placement (hipcc otherwise sinks the loads to the loop end).
-    f32x4 ra[2][WM], rb[2][WN];
+    f32x4 ra[2][PA], rb[2][PB];
     // per-tile uniform (fast path) / per-thread (generic) tap state produced by g_tap
     int g_kh = 0, g_kw = 0, g_coff = 0;
     unsigned g_bit = 0;
@@ -176,16 +178,20 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvP p, const int
     auto gload_all = [&](int kt, auto setc) {
         g_tap(kt);
 #pragma unroll
-        for (int i = 0; i < WM; ++i) g_a(i, setc);
+        for (int i = 0; i < PA; ++i) g_a(i, setc);
 #pragma unroll
-        for (int i = 0; i < WN; ++i) g_b(i, kt < nkt ? kt : nkt - 1, setc);
+        for (int i = 0; i < PB; ++i) g_b(i, kt < nkt ? kt : nkt - 1, setc);
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
 
-    f32x16 acc;
+    f32x16 acc[RM][RN];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int a = 0; a < RM; ++a)
+#pragma unroll
+        for (int b = 0; b < RN; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
     const int nk = kt1 - kt0;
     if (nk > 0) {
@@ -193,15 +199,16 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvP p, const int
         gload_all(kt0 + 1, I1{});                  // tile 1 -> set 1 (past the K range: zeros / last tile);
                                                    // issued before the first write-back so both latencies overlap
 #pragma unroll
-        for (int i = 0; i < WM; ++i) s_a(i, 0, I0{});
+        for (int i = 0; i < PA; ++i) s_a(i, 0, I0{});
 #pragma unroll
-        for (int i = 0; i < WN; ++i) s_b(i, 0, I0{});
+        for (int i = 0; i < PB; ++i) s_b(i, 0, I0{});
     }
     __syncthreads();
 
-    const int arow = (wm * 32 + (lane & 31)) * LDT + (lane >> 5) * 4;
-    const int brow = (wn * 32 + (lane & 31)) * LDT + (lane >> 5) * 4;
-    constexpr int NPIECE = WM + WN;
+    const int arow = (wm * RM * 32 + (lane & 31)) * LDT + (lane >> 5) * 4;
+    const int brow = (wn * RN * 32 + (lane & 31)) * LDT + (lane >> 5) * 4;
+    constexpr int NPIECE = PA + PB;
+    constexpr int NS = 16 * RM * RN;                  // MFMAs (= staging slots) per K tile
     // iteration `it`: C(it) from LDS buffer it&1; G(it+2) -> register set it&1;
     //                 S(it+1) from the other set -> LDS buffer (it+1)&1
     auto iteration = [&](int it, auto gsc) {
@@ -212,30 +219,38 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvP p, const int
         const int kt2c = kt2 < nkt ? kt2 : nkt - 1;    // weights: stay inside the [N][Kp] array
         const float *a_s = As + buf * BM * LDT + arow;
         const float *b_s = Bs + buf * BN * LDT + brow;
-        f32x4 fa[2], fb[2];
-        fa[0] = *reinterpret_cast<const f32x4 *>(a_s);
-        fb[0] = *reinterpret_cast<const f32x4 *>(b_s);
+        f32x4 fa[2][RM], fb[2][RN];
+#pragma unroll
+        for (int a = 0; a < RM; ++a) fa[0][a] = *reinterpret_cast<const f32x4 *>(a_s + a * 32 * LDT);
+#pragma unroll
+        for (int b = 0; b < RN; ++b) fb[0][b] = *reinterpret_cast<const f32x4 *>(b_s + b * 32 * LDT);
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
             const int cur = kb & 1;
-            if (kb < 3) {                              // prefetch the next fragment pair
-                fa[cur ^ 1] = *reinterpret_cast<const f32x4 *>(a_s + (kb + 1) * 8);
-                fb[cur ^ 1] = *reinterpret_cast<const f32x4 *>(b_s + (kb + 1) * 8);
+            if (kb < 3) {                              // prefetch the next fragments
+#pragma unroll
+                for (int a = 0; a < RM; ++a) fa[cur ^ 1][a] = *reinterpret_cast<const f32x4 *>(a_s + a * 32 * LDT + (kb + 1) * 8);
+#pragma unroll
+                for (int b = 0; b < RN; ++b) fb[cur ^ 1][b] = *reinterpret_cast<const f32x4 *>(b_s + b * 32 * LDT + (kb + 1) * 8);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][j], fb[cur][j], acc, 0, 0, 0);
-                // staging pieces between the MFMAs (unconditional: a branch per piece makes hipcc drain
-                // vmcnt(0) at every block boundary; on the tail iterations they fetch zeros / the last
-                // weight tile and write the unused LDS buffer, which is harmless)
-                const int slot = 4 * kb + j;
-                if (slot == 0) g_tap(kt2);
-                else if (slot <= WM) g_a(slot - 1, gsc);
-                else if (slot <= NPIECE) g_b(slot - 1 - WM, kt2c, gsc);
-                else if (slot >= 15 - NPIECE && slot < 15 - WN) s_a(slot - (15 - NPIECE), buf ^ 1, SS{});
-                else if (slot >= 15 - WN && slot < 15) s_b(slot - (15 - WN), buf ^ 1, SS{});
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int a = 0; a < RM; ++a)
+#pragma unroll
+                    for (int b = 0; b < RN; ++b) {
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][a][j], fb[cur][b][j], acc[a][b], 0, 0, 0);
+                        // staging pieces between the MFMAs (unconditional: a branch per piece makes hipcc drain
+                        // vmcnt(0) at every block boundary; on the tail iterations they fetch zeros / the last
+                        // weight tile and write the unused LDS buffer, which is harmless)
+                        const int slot = ((4 * kb + j) * RM + a) * RN + b;
+                        if (slot == 0) g_tap(kt2);
+                        else if (slot <= PA) g_a(slot - 1, gsc);
+                        else if (slot <= NPIECE) g_b(slot - 1 - PA, kt2c, gsc);
+                        else if (slot >= NS - 1 - NPIECE && slot < NS - 1 - PB) s_a(slot - (NS - 1 - NPIECE), buf ^ 1, SS{});
+                        else if (slot >= NS - 1 - PB && slot < NS - 1) s_b(slot - (NS - 1 - PB), buf ^ 1, SS{});
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
         }
         __syncthreads();
     };
@@ -247,36 +262,42 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvP p, const int
     if (it < nk) iteration(it, I0{});
 
     // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const int n = tn * BN + wn * 32 + (lane & 31);
-    if (n >= p.N) return;
-    const int mbase = tm * BM + wm * 32 + 4 * (lane >> 5);
-    if (p.splitk > 1) {
-        float *dst = p.partial + (long)split * p.M * p.N;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = mbase + (r & 3) + 8 * (r >> 2);
-            if (m < p.M) dst[(long)m * p.N + n] = acc[r];
-        }
-        return;
-    }
-    const float bv = p.bias ? p.bias[n] : 0.f;
-    const bool needb = p.res != nullptr || p.y_bs != 0;
+    for (int ba = 0; ba < RM; ++ba)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m = mbase + (r & 3) + 8 * (r >> 2);
-        if (m < p.M) {
-            float v = acc[r] + bv;
-            long yo = (long)m * p.N + n;
-            if (needb) {
-                const int b = p.B == 1 ? 0 : m / ohw;
-                const long po = (long)(m - b * ohw) * p.N + n;
-                if (p.res) v += p.res[(long)b * p.res_bs + po];
-                if (p.y_bs) yo = (long)b * p.y_bs + po;
+        for (int bb = 0; bb < RN; ++bb) {
+            const int n = tn * BN + (wn * RN + bb) * 32 + (lane & 31);
+            if (n >= p.N) continue;
+            const int mbase = tm * BM + (wm * RM + ba) * 32 + 4 * (lane >> 5);
+            const f32x16 &c = acc[ba][bb];
+            if (p.splitk > 1) {
+                float *dst = p.partial + (long)split * p.M * p.N;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mbase + (r & 3) + 8 * (r >> 2);
+                    if (m < p.M) dst[(long)m * p.N + n] = c[r];
+                }
+                continue;
             }
-            if (p.relu_out) v = fmaxf(v, 0.f);
-            p.y[yo] = v;
+            const float bv = p.bias ? p.bias[n] : 0.f;
+            const bool needb = p.res != nullptr || p.y_bs != 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mbase + (r & 3) + 8 * (r >> 2);
+                if (m < p.M) {
+                    float v = c[r] + bv;
+                    long yo = (long)m * p.N + n;
+                    if (needb) {
+                        const int b = p.B == 1 ? 0 : m / ohw;
+                        const long po = (long)(m - b * ohw) * p.N + n;
+                        if (p.res) v += p.res[(long)b * p.res_bs + po];
+                        if (p.y_bs) yo = (long)b * p.y_bs + po;
+                    }
+                    if (p.relu_out) v = fmaxf(v, 0.f);
+                    p.y[yo] = v;
+                }
+            }
         }
-    }
 }
 
 // y = sum_s partial[s] + bias (+res) (relu); 4 columns per thread
@@ -308,20 +329,42 @@ __global__ __launch_bounds__(256) void conv_reduce_kernel(const ConvP p) {
 }
 
 static inline bool narrow_variant(const ConvP &p) { return p.N <= 32; }
+static inline bool smallc_variant(const ConvP &p) {
+    return (p.Cin % 32) != 0 || (p.x1 && (p.c0 % 32) != 0) || p.KH * p.KW > 32;
+}
+// 128x128 workgroup tiles (each wave 2x2 accumulator blocks: half the LDS reads and staging per MFMA of the 64x64
+// tile; +8 % on a GEMM that fills the chip evenly) pay off for the deep-K GEMMs whose tiles fit one round of
+// workgroups; with more tiles the coarser grid loses more to the ragged last round than the loop gains.
+// STCN_CONV_BIG: 0 = never, 1 = that rule (default), 2 = also multi-round grids (several videos in flight fill
+// the ragged rounds of each other).
+static inline bool big_variant(const ConvP &p) {
+    static const int mode = [] { const char *e = getenv("STCN_CONV_BIG"); return e ? atoi(e) : 1; }();
+    if (mode == 0 || (p.mode & 1) || narrow_variant(p) || smallc_variant(p) || p.N < 256 || p.Kp < 2304) return false;
+    const long tiles = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    return mode >= 2 || tiles <= 256;
+}
+static inline void tile_shape(const ConvP &p, int &BM, int &BN) {
+    if (narrow_variant(p)) { BM = 128; BN = 32; }
+    else if (big_variant(p)) { BM = 128; BN = 128; }
+    else { BM = 64; BN = 64; }
+}
 
 int conv_choose_splitk(const ConvP &p) {
-    const int BM = narrow_variant(p) ? 128 : 64, BN = narrow_variant(p) ? 32 : 64;
+    int BM, BN;
+    tile_shape(p, BM, BN);
+    const int slots = 256;                                    // cost model unit: one workgroup per CU ("round")
     const long tiles = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     const int nkt = p.Kp / BK;
     const double mn = (double)p.M * p.N;
+    const double tile_cost = (double)(BM * BN) / (64 * 64);
     double best = 1e300;
     int best_s = 1;
     const int smax = nkt / 4 < 1 ? 1 : (nkt / 4 > 32 ? 32 : nkt / 4);
     for (int s = 1; s <= smax; ++s) {
         const int per = (nkt + s - 1) / s;
         if ((long)per * (s - 1) >= nkt) continue;  // an empty split
-        const long rounds = (tiles * s + 255) / 256;
-        double cost = (double)rounds * (per + 3.0);   // in K-tile times of one workgroup (~0.43 us)
+        const long rounds = (tiles * s + slots - 1) / slots;
+        double cost = (double)rounds * (per + 3.0) * tile_cost;   // in K-tile times of one 64x64 workgroup (~0.43 us)
         if (s > 1) cost += 4.6 + (s + 1) * 2.3e-6 * mn;
         if (cost < best) { best = cost; best_s = s; }
     }
@@ -332,37 +375,45 @@ size_t conv_workspace_floats(const ConvP &p) {
     return p.splitk > 1 ? (size_t)p.splitk * p.M * p.N : 0;
 }
 
+template <typename K>
+static void allow_big_lds(K kernel, size_t lds) {
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
 void conv_launch(const ConvP &p, hipStream_t s, hipEvent_t *ev_gemm, hipEvent_t *ev_red) {
-    const bool narrow = narrow_variant(p);
-    const int BM = narrow ? 128 : 64, BN = narrow ? 32 : 64;
+    const bool narrow = narrow_variant(p), big = big_variant(p);
+    int BM, BN;
+    tile_shape(p, BM, BN);
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
     const int ntile = tiles_m * tiles_n;
     const int nkt = p.Kp / BK;
     const int per = (nkt + p.splitk - 1) / p.splitk;
     const size_t lds = (size_t)2 * (BM + BN) * LDT * sizeof(float);
     const dim3 grid(ntile * p.splitk);
-    const bool smallc = (p.Cin % 32) != 0 || (p.x1 && (p.c0 % 32) != 0) || p.KH * p.KW > 32;
+    const bool smallc = smallc_variant(p);
     hipEvent_t e0 = ev_gemm ? ev_gemm[0] : nullptr, e1 = ev_gemm ? ev_gemm[1] : nullptr;
     if (p.mode & 1) {
         conv_f16x3_launch(p, tiles_n, ntile, per, grid, s, e0, e1);
     } else {
-#define STCN_LAUNCH(WM_, WN_, SC_, RL_)                                                                              \
-    do {                                                                                                              \
-        if (e0) hipExtLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, SC_, RL_>), grid, dim3(256), lds, s, e0, e1, 0, p,  \
-                                      tiles_n, ntile, per);                                                           \
-        else hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, SC_, RL_>), grid, dim3(256), lds, s, p, tiles_n, ntile,   \
-                                per);                                                                                 \
+#define STCN_LAUNCH(WM_, WN_, RM_, RN_, SC_, RL_)                                                                       \
+    do {                                                                                                                 \
+        auto kfn = conv_gemm_kernel<WM_, WN_, RM_, RN_, SC_, RL_>;                                                       \
+        allow_big_lds(kfn, lds);                                                                                         \
+        if (e0) hipExtLaunchKernelGGL(kfn, grid, dim3(256), lds, s, e0, e1, 0, p, tiles_n, ntile, per);                  \
+        else hipLaunchKernelGGL(kfn, grid, dim3(256), lds, s, p, tiles_n, ntile, per);                                   \
     } while (0)
-    const int key = (narrow ? 4 : 0) | (smallc ? 2 : 0) | (p.relu_in ? 1 : 0);
+    const int key = (big ? 8 : 0) | (narrow ? 4 : 0) | (smallc ? 2 : 0) | (p.relu_in ? 1 : 0);
     switch (key) {
-        case 0: STCN_LAUNCH(2, 2, false, false); break;
-        case 1: STCN_LAUNCH(2, 2, false, true); break;
-        case 2: STCN_LAUNCH(2, 2, true, false); break;
-        case 3: STCN_LAUNCH(2, 2, true, true); break;
-        case 4: STCN_LAUNCH(4, 1, false, false); break;
-        case 5: STCN_LAUNCH(4, 1, false, true); break;
-        case 6: STCN_LAUNCH(4, 1, true, false); break;
-        default: STCN_LAUNCH(4, 1, true, true); break;
+        case 0: STCN_LAUNCH(2, 2, 1, 1, false, false); break;
+        case 1: STCN_LAUNCH(2, 2, 1, 1, false, true); break;
+        case 2: STCN_LAUNCH(2, 2, 1, 1, true, false); break;
+        case 3: STCN_LAUNCH(2, 2, 1, 1, true, true); break;
+        case 4: STCN_LAUNCH(4, 1, 1, 1, false, false); break;
+        case 5: STCN_LAUNCH(4, 1, 1, 1, false, true); break;
+        case 6: STCN_LAUNCH(4, 1, 1, 1, true, false); break;
+        case 7: STCN_LAUNCH(4, 1, 1, 1, true, true); break;
+        case 8: STCN_LAUNCH(2, 2, 2, 2, false, false); break;
+        default: STCN_LAUNCH(2, 2, 2, 2, false, true); break;
     }
     }
 #undef STCN_LAUNCH

@@ -58,7 +58,11 @@ def main():
     sweep = "--sweep" in sys.argv
     sweep_gain = [0.0]
     print(f"{'layer':30s} {'M':>7s} {'N':>5s} {'K':>6s} {'ms':>8s} {'TFLOP/s':>8s} {'ms/frame':>9s}")
-    for name, B, H, W, Cin, Cout, K, st, cnt in SHAPES:
+    shapes = SHAPES
+    if "--shape" in sys.argv:           # --shape B,H,W,Cin,Cout,K,stride  (ad-hoc shape)
+        v = [int(x) for x in sys.argv[sys.argv.index("--shape") + 1].split(",")]
+        shapes = [("custom", *v, 1)]
+    for name, B, H, W, Cin, Cout, K, st, cnt in shapes:
         if only and only not in name:
             continue
         if batch:
