@@ -107,6 +107,32 @@ def test_full_resolution_round_trip_properties(nets):
     assert 0.05 < frac < 0.95
 
 
+def test_full_resolution_two_rounds_match_the_oracle(nets, weights):
+    """BASELINE size end to end against the CPU oracle (about 20 s of host time): interact(0) then interact(5) with
+    fusion on 480x854 - the north_star bars: masks within 1e-3 IoU, J&F within 0.1 (here: of each other, both
+    measured against the synthetic ground truth with the GPU J/F kernel and the CPU metrics)."""
+    from eva_vos_amd import metrics
+    T, H, W = 7, 480, 854
+    img, msk = synth.synthetic_clip(T, H, W), synth.synthetic_mask(T, H, W, 1)
+    core = make_core(nets)(img, 1, 3)
+    orc = O.OracleCore(weights[0], weights[1], img, 1, mem_freq=3)
+    for idx in (0, 5):
+        a, b = core.interact(msk[:, idx], idx), orc.interact(msk[:, idx], idx)
+        assert iou(a > 0, b > 0) >= 1 - 1e-3, idx
+        d = (core.prob.cpu() - orc.prob).abs().numpy()
+        q = [float(np.quantile(d, v)) for v in (0.5, 0.99, 0.999)]
+        print(f"full-res round idx={idx}: |prob diff| median {q[0]:.1e} q99 {q[1]:.1e} q999 {q[2]:.1e} max {d.max():.1e}")
+        # ~1620 queries x top-50 over thousands of bank rows: a few near-tie memberships differ between two fp32
+        # implementations (see check_sequence_against_golden); the bulk agrees to 1e-3
+        assert q[1] < 2e-3 and q[2] < 5e-2, (idx, q)
+    assert core.stats()["fused"] == 4
+    gt = msk[0, :, 0].numpy() > 0.5
+    jf_gpu = metrics.sequence_scores_gpu(torch.from_numpy(gt).cuda(), torch.from_numpy(a > 0).cuda())
+    jf_cpu = metrics.sequence_scores(gt, b > 0)
+    assert np.abs(jf_gpu[:, 2] - jf_cpu[:, 3]).max() < 0.1              # CPU rows are (frame, J, F, J&F)
+    assert abs(jf_gpu[:, 2].mean() - jf_cpu[:, 3].mean()) < 2e-3
+
+
 def test_config3_multi_object_full_bank_properties(nets):
     """BASELINE config 3 shape (480p, k=3 through the scribble/(k+1)-channel path, mem_freq=1: every frame
     enters the bank): bank growth, probability simplex, determinism, object exclusivity of the masks."""
