@@ -75,11 +75,30 @@ def cpu_baseline(psd, fsd, H, W, frames, mem_freq):
     torch.set_num_threads(best_t)
     core = OracleCore(psd, fsd, img, 1, mem_freq=mem_freq)
     t0 = time.perf_counter()
-    core.interact(msk[:, 0], 0)
+    ref_masks = core.interact(msk[:, 0], 0)
     dt = time.perf_counter() - t0
-    return dict(value=(frames - 1) / dt, unit="frames/s", cores=torch.get_num_threads(), kind="port",
+    base = dict(value=(frames - 1) / dt, unit="frames/s", cores=torch.get_num_threads(), kind="port",
                 sample=f"oracle OracleCore.interact(mask,0) on a {frames}-frame {H}x{W} synthetic clip "
                        f"({frames - 1} propagated frames, {dt:.1f} s, torch {torch.__version__} CPU)")
+    return base, (img, msk, ref_masks)
+
+
+def parity_vs_oracle(prop, fuse, sample, mem_freq):
+    """The HIP engine on the clip the CPU oracle just processed: mask IoU between the two and J&F of each against the
+    synthetic ground truth (north_star: masks within 1e-3 IoU, J&F within 0.1 of the CPU reference)."""
+    from eva_vos_amd import metrics
+    from mivos.inference_core import InferenceCore
+    img, msk, ref_masks = sample
+    got = InferenceCore(prop, fuse, img.cuda(), 1, mem_freq=mem_freq).interact(msk[:, 0], 0)
+    a, b = got > 0, ref_masks > 0
+    union = (a | b).sum()
+    gt = (msk[0, :, 0] > 0.5).cuda()
+    jf_gpu = metrics.sequence_scores_gpu(gt, torch.from_numpy(a).cuda())[1:, 2].mean()
+    jf_cpu = metrics.sequence_scores_gpu(gt, torch.from_numpy(b).cuda())[1:, 2].mean()
+    return dict(clip=f"{img.shape[1]} frames {img.shape[-2]}x{img.shape[-1]} (the cpu_baseline sample)",
+                mask_iou_hip_vs_cpu_oracle=float((a & b).sum() / union) if union else 1.0,
+                mask_pixels_differing=int((a != b).sum()), mask_pixels_total=int(a.size),
+                j_and_f_hip=float(jf_gpu), j_and_f_cpu_oracle=float(jf_cpu))
 
 
 def main():
@@ -309,7 +328,8 @@ def main():
         else:
             out["roofline"] = None
         if world == 1 and a.cpu_frames > 1:
-            out["cpu_baseline"] = cpu_baseline(psd, fsd, H, W, a.cpu_frames, a.mem_freq)
+            out["cpu_baseline"], sample = cpu_baseline(psd, fsd, H, W, a.cpu_frames, a.mem_freq)
+            out["parity_vs_cpu_oracle"] = parity_vs_oracle(prop, fuse, sample, a.mem_freq)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
