@@ -23,6 +23,8 @@
 //   * XCD-aware block remap: each XCD (own L2) gets a contiguous range of (m-tile, n-tile) pairs.
 #include <hip/hip_ext.h>
 
+#include <mutex>
+#include <set>
 #include <type_traits>
 
 #include "kernels.h"
@@ -375,9 +377,14 @@ size_t conv_workspace_floats(const ConvP &p) {
     return p.splitk > 1 ? (size_t)p.splitk * p.M * p.N : 0;
 }
 
-template <typename K>
-static void allow_big_lds(K kernel, size_t lds) {
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+// dynamic LDS above 64 KB has to be opted into once per kernel function (one process drives one GPU)
+static void allow_big_lds(const void *kernel, size_t lds) {
+    if (lds <= 64 * 1024) return;
+    static std::mutex mu;
+    static std::set<const void *> done;
+    std::lock_guard<std::mutex> g(mu);
+    if (done.insert(kernel).second)
+        (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 void conv_launch(const ConvP &p, hipStream_t s, hipEvent_t *ev_gemm, hipEvent_t *ev_red) {
@@ -398,7 +405,7 @@ void conv_launch(const ConvP &p, hipStream_t s, hipEvent_t *ev_gemm, hipEvent_t 
 #define STCN_LAUNCH(WM_, WN_, RM_, RN_, SC_, RL_)                                                                       \
     do {                                                                                                                 \
         auto kfn = conv_gemm_kernel<WM_, WN_, RM_, RN_, SC_, RL_>;                                                       \
-        allow_big_lds(kfn, lds);                                                                                         \
+        allow_big_lds(reinterpret_cast<const void *>(kfn), lds);                                                         \
         if (e0) hipExtLaunchKernelGGL(kfn, grid, dim3(256), lds, s, e0, e1, 0, p, tiles_n, ntile, per);                  \
         else hipLaunchKernelGGL(kfn, grid, dim3(256), lds, s, p, tiles_n, ntile, per);                                   \
     } while (0)
