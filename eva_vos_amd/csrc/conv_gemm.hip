@@ -23,6 +23,8 @@
 //   * XCD-aware block remap: each XCD (own L2) gets a contiguous range of (m-tile, n-tile) pairs.
 #include <hip/hip_ext.h>
 
+#include <cstdio>
+#include <cstdlib>
 #include <mutex>
 #include <set>
 #include <type_traits>
@@ -51,11 +53,30 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvP p, const int
     float *Bs = smem + 2 * BM * LDT;   // [2][BN][LDT]
 
     // ---- block -> (split, m-tile, n-tile), XCD-contiguous (bijective remap)
-    const int nblk = gridDim.x, bid = blockIdx.x;
-    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
-    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int split = swz / ntile;
-    const int tile = swz - split * ntile;
+    auto xcd_contiguous = [](int bid, int nblk) {       // block id -> position in a per-XCD contiguous order
+        const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+        return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    };
+    int split, tile, kper = kt_per_split;
+    bool piece = false;                                // tail balancing: this workgroup computes a K piece of a tile
+    if (p.rem_split > 1) {                             // blocks [0, rem_full): whole tiles; then the pieces
+        const int bid = blockIdx.x;
+        if (bid < p.rem_full) {
+            tile = xcd_contiguous(bid, p.rem_full);
+            split = 0;
+        } else {
+            const int j = xcd_contiguous(bid - p.rem_full, (int)gridDim.x - p.rem_full);
+            const int rt = j / p.rem_split;
+            split = j - rt * p.rem_split;
+            tile = p.rem_full + rt;
+            kper = p.rem_per;
+            piece = true;
+        }
+    } else {
+        const int swz = xcd_contiguous(blockIdx.x, gridDim.x);
+        split = swz / ntile;
+        tile = swz - split * ntile;
+    }
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -103,8 +124,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvP p, const int
     }
 
     const int nkt = p.Kp / BK;
-    const int kt0 = split * kt_per_split;
-    const int kt1 = min(nkt, kt0 + kt_per_split);
+    const int kt0 = split * kper;
+    const int kt1 = min(nkt, kt0 + kper);
 
     // Filter-tap walk.  Fast path (Cin and c0 multiples of 32, <= 32 taps): a K tile lies inside one tap
     // and one source, so tap / source / channel base are workgroup-uniform and live in scalar registers.
@@ -269,9 +290,16 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvP p, const int
 #pragma unroll
         for (int bb = 0; bb < RN; ++bb) {
             const int n = tn * BN + (wn * RN + bb) * 32 + (lane & 31);
-            if (n >= p.N) continue;
+            if (n >= p.N && !piece) continue;
             const int mbase = tm * BM + (wm * RM + ba) * 32 + 4 * (lane >> 5);
             const f32x16 &c = acc[ba][bb];
+            if (piece) {                               // tile-local partial sums, all rows / columns
+                float *dst = p.partial + ((long)(tile - p.rem_full) * p.rem_split + split) * (BM * BN);
+                const int col = (wn * RN + bb) * 32 + (lane & 31), row0 = (wm * RM + ba) * 32 + 4 * (lane >> 5);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dst[(row0 + (r & 3) + 8 * (r >> 2)) * BN + col] = c[r];
+                continue;
+            }
             if (p.splitk > 1) {
                 float *dst = p.partial + (long)split * p.M * p.N;
 #pragma unroll
@@ -330,51 +358,100 @@ __global__ __launch_bounds__(256) void conv_reduce_kernel(const ConvP p) {
     }
 }
 
+// tail balancing: y(tile) = sum over the K pieces of the tile-local partials + epilogue; one block per 32 tile rows
+__global__ __launch_bounds__(256) void conv_reduce_tiles_kernel(const ConvP p, const int tiles_n, const int BM, const int BN) {
+    const int rows_per_blk = 1024 / BN;                          // 256 threads x 4 columns
+    const int blks_per_tile = BM / rows_per_blk;
+    const int rt = blockIdx.x / blks_per_tile, rb = blockIdx.x - rt * blks_per_tile;
+    const int tile = p.rem_full + rt;
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int e4 = threadIdx.x * 4;
+    const int row = rb * rows_per_blk + e4 / BN, col = e4 - (e4 / BN) * BN;
+    const int m = tm * BM + row, n = tn * BN + col;
+    if (m >= p.M || n >= p.N) return;
+    const float *src = p.partial + (long)rt * p.rem_split * (BM * BN) + row * BN + col;
+    f32x4 v = *reinterpret_cast<const f32x4 *>(src);
+    for (int s = 1; s < p.rem_split; ++s) v += *reinterpret_cast<const f32x4 *>(src + (long)s * (BM * BN));
+    if (p.bias) v += *reinterpret_cast<const f32x4 *>(p.bias + n);
+    long yo = (long)m * p.N + n;
+    if (p.res || p.y_bs) {
+        const int ohw = p.OH * p.OW;
+        const int b = p.B == 1 ? 0 : m / ohw;
+        const long po = (long)(m - b * ohw) * p.N + n;
+        if (p.res) v += *reinterpret_cast<const f32x4 *>(p.res + (long)b * p.res_bs + po);
+        if (p.y_bs) yo = (long)b * p.y_bs + po;
+    }
+    if (p.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    *reinterpret_cast<f32x4 *>(p.y + yo) = v;
+}
+
 static inline bool narrow_variant(const ConvP &p) { return p.N <= 32; }
 static inline bool smallc_variant(const ConvP &p) {
     return (p.Cin % 32) != 0 || (p.x1 && (p.c0 % 32) != 0) || p.KH * p.KW > 32;
 }
-// 128x128 workgroup tiles (each wave 2x2 accumulator blocks: half the LDS reads and staging per MFMA of the 64x64
-// tile; +8 % on a GEMM that fills the chip evenly) pay off for the deep-K GEMMs whose tiles fit one round of
-// workgroups; with more tiles the coarser grid loses more to the ragged last round than the loop gains.
-// STCN_CONV_BIG: 0 = never, 1 = that rule (default), 2 = also multi-round grids (several videos in flight fill
-// the ragged rounds of each other).
-static inline bool big_variant(const ConvP &p) {
-    static const int mode = [] { const char *e = getenv("STCN_CONV_BIG"); return e ? atoi(e) : 1; }();
-    if (mode == 0 || (p.mode & 1) || narrow_variant(p) || smallc_variant(p) || p.N < 256 || p.Kp < 2304) return false;
-    const long tiles = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-    return mode >= 2 || tiles <= 256;
-}
-static inline void tile_shape(const ConvP &p, int &BM, int &BN) {
-    if (narrow_variant(p)) { BM = 128; BN = 32; }
-    else if (big_variant(p)) { BM = 128; BN = 128; }
-    else { BM = 64; BN = 64; }
-}
+// ---- launch plan ---------------------------------------------------------------------------------------------
+// Cost model in K-tile times of one 64x64 workgroup (~0.45 us): the chip runs "rounds" of 256 workgroups (one per CU;
+// co-resident workgroups of a CU share its MFMA pipes, so only the count per CU matters), a workgroup costs its K tiles
+// plus ~3 for prologue / epilogue.  Candidates:
+//   * tile 64x64 (128x32 for Cout <= 32); 128x128 tiles (each wave 2x2 accumulator blocks: half the LDS reads and staging
+//     per MFMA, +8 % on a GEMM that fills the chip evenly) are opt-in (STCN_CONV_BIG=1 lets the model choose, 2 forces
+//     them for deep-K GEMMs): once the tails are balanced they win on none of this path's shapes by more than 3 %;
+//   * plain split-K s (slabs + conv_reduce_kernel) when the tiles do not fill the chip;
+//   * tail balancing when they fill it more than once: the whole rounds run unsplit and only the tiles of the ragged
+//     last round are cut into K pieces (1620 tiles = 6 rounds + 84 tiles x 3 pieces instead of 7 rounds).
+// STCN_CONV_TAIL=0 switches the tail balancing off.
+struct Plan { double cost; int big, splitk, rem_full, rem_split, rem_per; };
 
-int conv_choose_splitk(const ConvP &p) {
-    int BM, BN;
-    tile_shape(p, BM, BN);
-    const int slots = 256;                                    // cost model unit: one workgroup per CU ("round")
+static Plan plan_variant(const ConvP &p, bool big, int force_splitk, size_t ws_floats) {
+    static const bool tail_on = [] { const char *e = getenv("STCN_CONV_TAIL"); return !e || atoi(e) != 0; }();
+    const int BM = narrow_variant(p) ? 128 : (big ? 128 : 64), BN = narrow_variant(p) ? 32 : (big ? 128 : 64);
     const long tiles = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     const int nkt = p.Kp / BK;
     const double mn = (double)p.M * p.N;
-    const double tile_cost = (double)(BM * BN) / (64 * 64);
-    double best = 1e300;
-    int best_s = 1;
+    const double tile_cost = (double)(BM * BN) / (64 * 64) * (big ? 0.92 : 1.0);
+    Plan best{1e300, big ? 1 : 0, 1, 0, 0, 0};
     const int smax = nkt / 4 < 1 ? 1 : (nkt / 4 > 32 ? 32 : nkt / 4);
     for (int s = 1; s <= smax; ++s) {
+        if (force_splitk > 0 && s != force_splitk && !(force_splitk > smax && s == smax)) continue;
         const int per = (nkt + s - 1) / s;
         if ((long)per * (s - 1) >= nkt) continue;  // an empty split
-        const long rounds = (tiles * s + slots - 1) / slots;
-        double cost = (double)rounds * (per + 3.0) * tile_cost;   // in K-tile times of one 64x64 workgroup (~0.43 us)
+        if (s > 1 && (size_t)s * p.M * p.N > ws_floats) continue;
+        const long rounds = (tiles * s + 255) / 256;
+        // a workgroup alone on its CU has nobody to hide its load / barrier latencies behind (measured: +20 %)
+        const double lone = tiles * s <= 256 ? 1.2 : (tiles * s <= 512 ? 1.04 : 1.0);
+        double cost = (double)rounds * (per + 3.0) * tile_cost * lone;
         if (s > 1) cost += 4.6 + (s + 1) * 2.3e-6 * mn;
-        if (cost < best) { best = cost; best_s = s; }
+        if (cost < best.cost) best = Plan{cost, big ? 1 : 0, s, 0, 0, 0};
     }
-    return best_s;
+    const long full_rounds = tiles / 256, n_rem = tiles - full_rounds * 256;
+    if (tail_on && force_splitk <= 0 && !(p.mode & 1) && full_rounds >= 1 && n_rem > 0 && nkt >= 8) {
+        for (int sr = 2; sr <= 8 && sr <= nkt / 4; ++sr) {
+            const int per = (nkt + sr - 1) / sr;
+            if ((long)per * (sr - 1) >= nkt) continue;
+            const long pieces = n_rem * sr;
+            if ((size_t)pieces * BM * BN > ws_floats) continue;
+            const double cost = ((double)full_rounds * (nkt + 3.0) + (double)((pieces + 255) / 256) * (per + 3.0)) * tile_cost +
+                                4.6 + (sr + 1) * 2.3e-6 * (double)n_rem * BM * BN;
+            if (cost < best.cost) best = Plan{cost, big ? 1 : 0, 1, (int)(full_rounds * 256), sr, per};
+        }
+    }
+    return best;
 }
 
-size_t conv_workspace_floats(const ConvP &p) {
-    return p.splitk > 1 ? (size_t)p.splitk * p.M * p.N : 0;
+void conv_plan(ConvP &p, int force_splitk, size_t ws_floats) {
+    static const int big_mode = [] { const char *e = getenv("STCN_CONV_BIG"); return e ? atoi(e) : 0; }();
+    Plan pl = plan_variant(p, false, force_splitk, ws_floats);
+    const bool big_ok = big_mode != 0 && !(p.mode & 1) && !narrow_variant(p) && !smallc_variant(p) && p.N >= 256 && p.Kp >= 2304;
+    if (big_ok) {
+        const Plan pb = plan_variant(p, true, force_splitk, ws_floats);
+        if (pb.cost < pl.cost || big_mode >= 2) pl = pb;
+    }
+    p.tile_big = pl.big; p.splitk = pl.splitk;
+    p.rem_full = pl.rem_full; p.rem_split = pl.rem_split; p.rem_per = pl.rem_per;
+    static const bool dbg = getenv("STCN_CONV_PLAN_DEBUG") != nullptr;
+    if (dbg)
+        fprintf(stderr, "conv_plan M=%d N=%d K=%d: %s splitk=%d tail=(%d full, %d pieces of %d) cost %.0f\n", p.M, p.N, p.Kp,
+                pl.big ? "128x128" : (narrow_variant(p) ? "128x32" : "64x64"), pl.splitk, pl.rem_full, pl.rem_split, pl.rem_per, pl.cost);
 }
 
 // dynamic LDS above 64 KB has to be opted into once per kernel function (one process drives one GPU)
@@ -388,15 +465,15 @@ static void allow_big_lds(const void *kernel, size_t lds) {
 }
 
 void conv_launch(const ConvP &p, hipStream_t s, hipEvent_t *ev_gemm, hipEvent_t *ev_red) {
-    const bool narrow = narrow_variant(p), big = big_variant(p);
-    int BM, BN;
-    tile_shape(p, BM, BN);
+    const bool narrow = narrow_variant(p), big = p.tile_big != 0;
+    const int BM = narrow ? 128 : (big ? 128 : 64), BN = narrow ? 32 : (big ? 128 : 64);
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
     const int ntile = tiles_m * tiles_n;
     const int nkt = p.Kp / BK;
     const int per = (nkt + p.splitk - 1) / p.splitk;
     const size_t lds = (size_t)2 * (BM + BN) * LDT * sizeof(float);
-    const dim3 grid(ntile * p.splitk);
+    const bool tail = p.rem_split > 1;
+    const dim3 grid(tail ? p.rem_full + (ntile - p.rem_full) * p.rem_split : ntile * p.splitk);
     const bool smallc = smallc_variant(p);
     hipEvent_t e0 = ev_gemm ? ev_gemm[0] : nullptr, e1 = ev_gemm ? ev_gemm[1] : nullptr;
     if (p.mode & 1) {
@@ -424,7 +501,13 @@ void conv_launch(const ConvP &p, hipStream_t s, hipEvent_t *ev_gemm, hipEvent_t 
     }
     }
 #undef STCN_LAUNCH
-    if (p.splitk > 1) {
+    if (tail) {
+        const unsigned blocks = (unsigned)((ntile - p.rem_full) * (BM * BN / 1024));
+        if (ev_red)
+            hipExtLaunchKernelGGL(conv_reduce_tiles_kernel, dim3(blocks), dim3(256), 0, s, ev_red[0], ev_red[1], 0, p, tiles_n, BM, BN);
+        else
+            hipLaunchKernelGGL(conv_reduce_tiles_kernel, dim3(blocks), dim3(256), 0, s, p, tiles_n, BM, BN);
+    } else if (p.splitk > 1) {
         const long total4 = (long)p.M * p.N / 4;
         long blocks = (total4 + 255) / 256;
         if (blocks > 2048) blocks = 2048;

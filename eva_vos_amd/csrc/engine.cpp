@@ -313,9 +313,8 @@ int run_conv(const Model &m, Work &w, hipStream_t s, const char *name, const flo
     p.mode = ((m.precision & 1) && cw.w_hi) ? 1 : 0;
     p.bias = cw.bias; p.res = res; p.res_bs = res_bs; p.y = y; p.y_bs = y_bs;
     p.relu_in = relu_in; p.relu_out = relu_out;
-    p.splitk = force_splitk > 0 ? force_splitk : conv_choose_splitk(p);
-    while (p.splitk > 1 && (size_t)p.splitk * p.M * p.N > w.splitk_floats) --p.splitk;
     p.partial = w.splitk;
+    conv_plan(p, force_splitk, w.splitk_floats);
     const double fl = 2.0 * p.M * p.N * (double)(cw.kh * cw.kw * cw.cin);
     if (w.prof)   // algorithmic bytes: input(s), weights, output and residual once each
         w.prof->bytes[STCN_K_CONV] += 4.0 * ((double)p.x0_bytes / 4 + (double)p.x1_bytes / 4 + (double)cw.cout * cw.K +
@@ -324,7 +323,7 @@ int run_conv(const Model &m, Work &w, hipStream_t s, const char *name, const flo
     if (w.prof) {
         w.prof->flops[STCN_K_CONV] += fl;
         eg = w.prof->attach(STCN_K_CONV);
-        if (p.splitk > 1) er = w.prof->attach(STCN_K_CONV_REDUCE);
+        if (p.splitk > 1 || p.rem_split > 1) er = w.prof->attach(STCN_K_CONV_REDUCE);
     }
     conv_launch(p, s, eg, er);
     return STCN_OK;

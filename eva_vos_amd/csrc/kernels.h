@@ -30,13 +30,18 @@ struct ConvP {
     int relu_in, relu_out;
     int splitk;             // >= 1
     float *partial;         // [splitk][M][N] workspace when splitk > 1
+    // tail balancing (splitk == 1 only, see conv_plan): tiles [0, rem_full) run whole; each of the remaining tiles is
+    // cut into rem_split K pieces of rem_per K tiles whose tile-local partial sums go to `partial`
+    // ([(tile - rem_full) * rem_split + piece][BM][BN]) and are summed by conv_reduce_tiles_kernel
+    int rem_full, rem_split, rem_per;
+    int tile_big;           // 1 = 128x128 workgroup tiles (fp32 kernel)
 };
-// picks the tile variant; returns the split-K it used
-int  conv_choose_splitk(const ConvP &p);
+// fills the launch plan of p (tile variant, split-K or tail balancing); force_splitk > 0 pins a plain split-K;
+// workspace_floats = capacity of p.partial
+void conv_plan(ConvP &p, int force_splitk, size_t workspace_floats);
 // ev_gemm / ev_red: optional {start, stop} event pairs attached to the GEMM / reduce dispatches themselves
 // (hipExtLaunchKernelGGL: kernel begin/end timestamps, no extra barrier packets)
 void conv_launch(const ConvP &p, hipStream_t s, hipEvent_t *ev_gemm = nullptr, hipEvent_t *ev_red = nullptr);
-size_t conv_workspace_floats(const ConvP &p);
 void conv_f16x3_launch(const ConvP &p, int tiles_n, int ntile, int per, dim3 grid, hipStream_t s, hipEvent_t e0,
                        hipEvent_t e1);
 static constexpr float CONV_F16_ASCALE = 4.f;
