@@ -11,6 +11,7 @@ engine on the current HIP stream.  PyTorch is used for device memory and stream 
 from __future__ import annotations
 
 import ctypes as C
+import threading
 import weakref
 
 import numpy as np
@@ -49,12 +50,16 @@ class _Model:
         self._finalizer = weakref.finalize(self, lib.stcn_model_destroy, h)
 
 
+_MODEL_LOCK = threading.Lock()
+
+
 def _model_for(prop_net, fuse_net, device_index: int) -> _Model:
-    per_net = _MODEL_CACHE.setdefault(prop_net, {})
-    key = (id(fuse_net), device_index)
-    if key not in per_net:
-        per_net[key] = _Model(prop_net, fuse_net, device_index)
-    return per_net[key]
+    with _MODEL_LOCK:                       # engines may be created from several host threads (one per video)
+        per_net = _MODEL_CACHE.setdefault(prop_net, {})
+        key = (id(fuse_net), device_index)
+        if key not in per_net:
+            per_net[key] = _Model(prop_net, fuse_net, device_index)
+        return per_net[key]
 
 
 def _pad16(n: int):
