@@ -130,11 +130,22 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvP p, const int
     // Filter-tap walk.  Fast path (Cin and c0 multiples of 32, <= 32 taps): a K tile lies inside one tap
     // and one source, so tap / source / channel base are workgroup-uniform and live in scalar registers.
     // Generic path (stems, Cin = 4/8/12): per-thread decode of its 4-channel chunk.
+    // The fast path walks K as (channel block, kh, kw) with the TAP fastest, not in the weights' memory order
+    // (kh, kw, channel): the 9 taps of a 32-channel block touch the same three image rows within 9 consecutive K
+    // tiles, so the im2col re-reads hit L1 / L2.  In (kh, kw, channel) order the three kh phases of a 3x3 conv are
+    // a third of the kernel apart and every input row came from beyond L2 three times (FETCH_SIZE 2.6x the input).
+    // Only the visiting order changes: K tile position q -> weight K tile (tap * Cin/32 + channel block).
+    const int ncb = p.Cin / BK, ntap = p.KH * p.KW;
     int u_kh, u_kw, u_cb;
-    {
+    if (SMALLC) {
         const int k0 = kt0 * BK;
         const int tap = k0 / p.Cin;
         u_cb = k0 - tap * p.Cin;
+        u_kh = tap / p.KW;
+        u_kw = tap - u_kh * p.KW;
+    } else {
+        const int cbi = kt0 / ntap, tap = kt0 - cbi * ntap;
+        u_cb = cbi * BK;
         u_kh = tap / p.KW;
         u_kw = tap - u_kh * p.KW;
     }
@@ -147,12 +158,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvP p, const int
     //   write-back; sched_barrier pins the placement (hipcc otherwise sinks the loads to the loop end).
     f32x4 ra[2][PA], rb[2][PB];
     // per-tile uniform (fast path) / per-thread (generic) tap state produced by g_tap
-    int g_kh = 0, g_kw = 0, g_coff = 0;
+    int g_kh = 0, g_kw = 0, g_coff = 0, g_wkt = 0;     // g_wkt: K tile of the weight array for this position
     unsigned g_bit = 0;
     bool g_src1 = false, g_kvalid = true;
     auto g_tap = [&](int kt) {
         if (SMALLC) {
             const int k = kt * BK + kc * 4;
+            g_wkt = kt < nkt ? kt : nkt - 1;
             g_kvalid = k < p.K;
             const int tap = k / p.Cin;
             const int c = k - tap * p.Cin;
@@ -164,8 +176,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvP p, const int
             g_bit = (unsigned)(u_kh * p.KW + u_kw);
             const int cs = g_src1 ? p.c1 : p.c0;
             g_coff = ((u_kh * p.W + u_kw) * cs + (g_src1 ? u_cb - p.c0 : u_cb)) * 4;
-            u_cb += BK;
-            if (u_cb >= p.Cin) { u_cb = 0; if (++u_kw == p.KW) { u_kw = 0; ++u_kh; } }
+            g_wkt = min((int)g_bit * ncb + u_cb / BK, nkt - 1);          // past the K range: stay inside [N][Kp]
+            if (++u_kw == p.KW) { u_kw = 0; if (++u_kh == p.KH) { u_kh = 0; u_cb += BK; } }
         }
     };
     auto g_a = [&](int i, auto setc) {
@@ -182,9 +194,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvP p, const int
             ra[ST][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_src1 ? rs1 : rs0, voff, 0, 0));
         }
     };
-    auto g_b = [&](int i, int kt, auto setc) {
+    auto g_b = [&](int i, auto setc) {
         constexpr int ST = decltype(setc)::value;
-        rb[ST][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, woff[i], kt * (BK * 4), 0));
+        rb[ST][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, woff[i], g_wkt * (BK * 4), 0));
     };
     float *const a_st = As + r0 * LDT + kc * 4;
     float *const b_st = Bs + r0 * LDT + kc * 4;
@@ -203,7 +215,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvP p, const int
 #pragma unroll
         for (int i = 0; i < PA; ++i) g_a(i, setc);
 #pragma unroll
-        for (int i = 0; i < PB; ++i) g_b(i, kt < nkt ? kt : nkt - 1, setc);
+        for (int i = 0; i < PB; ++i) g_b(i, setc);
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
@@ -239,7 +251,6 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvP p, const int
         using SS = std::integral_constant<int, GS ^ 1>;
         constexpr int buf = GS;
         const int kt2 = kt0 + it + 2;
-        const int kt2c = kt2 < nkt ? kt2 : nkt - 1;    // weights: stay inside the [N][Kp] array
         const float *a_s = As + buf * BM * LDT + arow;
         const float *b_s = Bs + buf * BN * LDT + brow;
         f32x4 fa[2][RM], fb[2][RN];
@@ -269,7 +280,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvP p, const int
                         const int slot = ((4 * kb + j) * RM + a) * RN + b;
                         if (slot == 0) g_tap(kt2);
                         else if (slot <= PA) g_a(slot - 1, gsc);
-                        else if (slot <= NPIECE) g_b(slot - 1 - PA, kt2c, gsc);
+                        else if (slot <= NPIECE) g_b(slot - 1 - PA, gsc);
                         else if (slot >= NS - 1 - NPIECE && slot < NS - 1 - PB) s_a(slot - (NS - 1 - NPIECE), buf ^ 1, SS{});
                         else if (slot >= NS - 1 - PB && slot < NS - 1) s_b(slot - (NS - 1 - PB), buf ^ 1, SS{});
                         __builtin_amdgcn_sched_barrier(0);

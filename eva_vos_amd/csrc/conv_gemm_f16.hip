@@ -93,23 +93,31 @@ __global__ __launch_bounds__(256) void conv_gemm_f16x3_kernel(const ConvP p, con
     const int kt0 = split * kt_per_split;
     const int kt1 = min(nkt, kt0 + kt_per_split);
 
+    // fast path: K is walked as (channel block, kh, kw), tap fastest (see conv_gemm.hip)
+    const int ncb = p.Cin / BK, ntap = p.KH * p.KW;
     int u_kh, u_kw, u_cb;
-    {
+    if (SMALLC) {
         const int k0 = kt0 * BK;
         const int tap = k0 / p.Cin;
         u_cb = k0 - tap * p.Cin;
+        u_kh = tap / p.KW;
+        u_kw = tap - u_kh * p.KW;
+    } else {
+        const int cbi = kt0 / ntap, tap = kt0 - cbi * ntap;
+        u_cb = cbi * BK;
         u_kh = tap / p.KW;
         u_kw = tap - u_kh * p.KW;
     }
 
     f32x4 ra[2][WM];
     u32x4 rbh[2], rbl[2];
-    int g_kh = 0, g_kw = 0, g_coff = 0;
+    int g_kh = 0, g_kw = 0, g_coff = 0, g_wkt = 0;
     unsigned g_bit = 0;
     bool g_src1 = false, g_kvalid = true;
     auto g_tap = [&](int kt) {
         if (SMALLC) {
             const int k = kt * BK + kc * 4;
+            g_wkt = kt < nkt ? kt : nkt - 1;
             g_kvalid = k < p.K;
             const int tap = k / p.Cin;
             const int c = k - tap * p.Cin;
@@ -121,8 +129,8 @@ __global__ __launch_bounds__(256) void conv_gemm_f16x3_kernel(const ConvP p, con
             g_bit = (unsigned)(u_kh * p.KW + u_kw);
             const int cs = g_src1 ? p.c1 : p.c0;
             g_coff = ((u_kh * p.W + u_kw) * cs + (g_src1 ? u_cb - p.c0 : u_cb)) * 4;
-            u_cb += BK;
-            if (u_cb >= p.Cin) { u_cb = 0; if (++u_kw == p.KW) { u_kw = 0; ++u_kh; } }
+            g_wkt = min((int)g_bit * ncb + u_cb / BK, nkt - 1);
+            if (++u_kw == p.KW) { u_kw = 0; if (++u_kh == p.KH) { u_kh = 0; u_cb += BK; } }
         }
     };
     auto g_a = [&](int i, auto setc) {
@@ -139,10 +147,10 @@ __global__ __launch_bounds__(256) void conv_gemm_f16x3_kernel(const ConvP p, con
             ra[ST][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_src1 ? rs1 : rs0, voff, 0, 0));
         }
     };
-    auto g_b = [&](int kt, auto setc) {
+    auto g_b = [&](auto setc) {
         constexpr int ST = decltype(setc)::value;
-        rbh[ST] = __builtin_amdgcn_raw_buffer_load_b128(rwh, woff, kt * (BK * 2), 0);
-        rbl[ST] = __builtin_amdgcn_raw_buffer_load_b128(rwl, woff, kt * (BK * 2), 0);
+        rbh[ST] = __builtin_amdgcn_raw_buffer_load_b128(rwh, woff, g_wkt * (BK * 2), 0);
+        rbl[ST] = __builtin_amdgcn_raw_buffer_load_b128(rwl, woff, g_wkt * (BK * 2), 0);
     };
     _Float16 *const a_st = Ah + r0 * LDH + kc * 4;
     _Float16 *const b_st = Bh + br * LDH + bc * 8;
@@ -168,7 +176,7 @@ __global__ __launch_bounds__(256) void conv_gemm_f16x3_kernel(const ConvP p, con
         g_tap(kt);
 #pragma unroll
         for (int i = 0; i < WM; ++i) g_a(i, setc);
-        g_b(kt < nkt ? kt : nkt - 1, setc);
+        g_b(setc);
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
@@ -195,7 +203,6 @@ __global__ __launch_bounds__(256) void conv_gemm_f16x3_kernel(const ConvP p, con
         using SS = std::integral_constant<int, GS ^ 1>;
         constexpr int buf = GS;
         const int kt2 = kt0 + it + 2;
-        const int kt2c = kt2 < nkt ? kt2 : nkt - 1;
         const _Float16 *ah = Ah + buf * BUF + arow, *al = ah + BM * LDH;
         const _Float16 *bh = Bh + buf * BUF + brow, *bl = bh + BN * LDH;
         half8 fah[2], fal[2], fbh[2], fbl[2];
@@ -213,7 +220,7 @@ __global__ __launch_bounds__(256) void conv_gemm_f16x3_kernel(const ConvP p, con
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[1], fbh[1], acc, 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < WM; ++i) g_a(i, gsc);
-        g_b(kt2c, gsc);
+        g_b(gsc);
         __builtin_amdgcn_sched_barrier(0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[0], fbl[0], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[1], fbl[1], acc, 0, 0, 0);
