@@ -546,6 +546,7 @@ int stcn_model_destroy(stcn_model *m) {
 
 // ---- engine -------------------------------------------------------------------------------------
 static int engine_init_outputs(stcn_engine *e);
+static int clone_state(stcn_engine *e, const stcn_engine *src);
 static int eng_alloc(stcn_engine *e, void **p, size_t bytes) {
     HIPCHK(hipMalloc(p, bytes));
     e->allocs.push_back(*p);
@@ -596,7 +597,10 @@ static int bank_reserve(stcn_engine *e, int slots) {
 
 static int engine_alloc_common(stcn_engine *e) {
     const Dims &d = e->d;
-    RC(eng_alloc(e, (void **)&e->images4, (size_t)e->T * d.npix * 4 * 4));
+    if (!e->images4) {                                     // a clone arrives with its source's packed clip
+        HIPCHK(hipMalloc((void **)&e->images4, (size_t)e->T * d.npix * 4 * 4));
+        e->images_owner = std::shared_ptr<void>(e->images4, [](void *p) { (void)hipFree(p); });
+    }
     e->n_slots = e->T < 106 ? e->T : 106;                 // key_buf holds at most 106 frames (inference_core.py:46,118)
     e->slot_floats = (size_t)d.hw16 * (64 + 512 + 1024) + (size_t)(d.hw16 + 3) / 4 * 4 + (size_t)d.hw8 * 512 + (size_t)d.hw4 * 256 +
                      (size_t)4 * d.hw16 * 512;
@@ -700,14 +704,21 @@ int stcn_engine_clone(const stcn_engine *src, float *prob_dev, uint8_t *masks_de
     e->T = src->T; e->H = src->H; e->W = src->W; e->k = src->k; e->mem_freq = src->mem_freq;
     e->lw = src->lw; e->uw = src->uw; e->lh = src->lh; e->uh = src->uh; e->d = src->d;
     e->prob = prob_dev; e->masks = masks_dev;
+    e->images4 = src->images4; e->images_owner = src->images_owner;      // read-only: shared, not copied
     int rc = engine_alloc_common(e);
     if (!rc) rc = bank_reserve(e, src->bank_cap);
+    if (!rc) rc = clone_state(e, src);
     if (rc) { stcn_engine_destroy(e); return rc; }
+    *out = e;
+    return STCN_OK;
+}
+
+static int clone_state(stcn_engine *e, const stcn_engine *src) {
     const Dims &d = e->d;
     HIPCHK(hipStreamSynchronize(src->stream));
     if (src->side) HIPCHK(hipStreamSynchronize(src->side));
-    HIPCHK(hipMemcpyAsync(e->images4, src->images4, (size_t)e->T * d.npix * 16, hipMemcpyDeviceToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(e->cache, src->cache, (size_t)e->n_slots * e->slot_floats * 4, hipMemcpyDeviceToDevice, e->stream));
+    // only the occupied key-cache slots (a clone per candidate frame is the upper-bound policy's inner loop)
+    HIPCHK(hipMemcpyAsync(e->cache, src->cache, (size_t)src->n_cached * e->slot_floats * 4, hipMemcpyDeviceToDevice, e->stream));
     e->slot_of = src->slot_of; e->n_cached = src->n_cached; e->vparts_ready = src->vparts_ready;
     e->n_certain = src->n_certain; e->interacted = src->interacted;
     const size_t crow = (size_t)e->n_certain * d.hw16;
@@ -722,7 +733,6 @@ int stcn_engine_clone(const stcn_engine *src, float *prob_dev, uint8_t *masks_de
     HIPCHK(hipMemcpyAsync(e->pos, src->pos, (size_t)(e->k + 1) * d.npix * 4, hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(e->neg, src->neg, (size_t)(e->k + 1) * d.npix * 4, hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    *out = e;
     return STCN_OK;
 }
 

@@ -4,6 +4,7 @@
 
 #include <deque>
 #include <map>
+#include <memory>
 #include <set>
 #include <string>
 #include <vector>
@@ -125,7 +126,8 @@ struct stcn_engine {
     int T = 0, H = 0, W = 0, k = 0, mem_freq = 5;
     int lw = 0, uw = 0, lh = 0, uh = 0;
     stcn::Dims d{};
-    float *images4 = nullptr;          // [T][nh][nw][4]
+    float *images4 = nullptr;          // [T][nh][nw][4]; immutable after create, shared with clones
+    std::shared_ptr<void> images_owner;  // frees images4 with the last engine that uses it
     float *prob = nullptr;             // caller-owned [k+1][T][npix]
     uint8_t *masks = nullptr;          // caller-owned [T][npix]
     // key-feature cache
