@@ -97,9 +97,9 @@ __device__ __forceinline__ void bil(int dst, float scale, int n, int &i0, int &i
     f = s - (float)i0;
 }
 
-// UpsampleBlock (modules.py:159-163): u[b] = skip_conv(skip) (batch-broadcast) + up2x(x[b])
+// UpsampleBlock (modules.py:159-163): u[b] = skip_conv(skip)[b * skip_bs] (skip_bs 0: batch-broadcast) + up2x(x[b])
 __global__ void upsample2x_add_kernel(const float *__restrict__ x, const float *__restrict__ skip,
-                                      float *__restrict__ u, int B, int h, int w, int C) {
+                                      float *__restrict__ u, int B, int h, int w, int C, long skip_bs) {
     const int OH = 2 * h, OW = 2 * w, C4 = C / 4;
     const long i = blockIdx.x * 256L + threadIdx.x;
     if (i >= (long)B * OH * OW * C4) return;
@@ -116,7 +116,7 @@ __global__ void upsample2x_add_kernel(const float *__restrict__ x, const float *
     const f32x4 v01 = *reinterpret_cast<const f32x4 *>(xb + ((long)y0 * w + x1) * C);
     const f32x4 v10 = *reinterpret_cast<const f32x4 *>(xb + ((long)y1 * w + x0) * C);
     const f32x4 v11 = *reinterpret_cast<const f32x4 *>(xb + ((long)y1 * w + x1) * C);
-    const f32x4 sk = *reinterpret_cast<const f32x4 *>(skip + ((long)oy * OW + ox) * C + c4 * 4);
+    const f32x4 sk = *reinterpret_cast<const f32x4 *>(skip + (long)b * skip_bs + ((long)oy * OW + ox) * C + c4 * 4);
     const float w00 = (1.f - fy) * (1.f - fx), w01 = (1.f - fy) * fx, w10 = fy * (1.f - fx), w11 = fy * fx;
     f32x4 o;
     o.x = sk.x + (w00 * v00.x + w01 * v01.x + w10 * v10.x + w11 * v11.x);
@@ -126,9 +126,9 @@ __global__ void upsample2x_add_kernel(const float *__restrict__ x, const float *
     *reinterpret_cast<f32x4 *>(u + i * 4) = o;
 }
 void upsample2x_add_launch(const float *x, const float *skip, float *u, int B, int h, int w, int C,
-                           hipStream_t s) {
+                           hipStream_t s, long skip_bs) {
     hipLaunchKernelGGL(upsample2x_add_kernel, dim3(nblocks((long)B * 4 * h * w * (C / 4))), dim3(256), 0, s, x,
-                       skip, u, B, h, w, C);
+                       skip, u, B, h, w, C, skip_bs);
 }
 
 // aggregate_wbg (aggregate.py:22-37) on up to 8 objects: odds / sum(odds) after clamping

@@ -251,7 +251,7 @@ static int build_model(Model &m, const stcn_weight_desc *prop, int n_prop, const
 }
 
 // ---------------------------------------------------------------------------------------------- Work
-int Work::init(int nh, int nw, int k_, int key_batch) {
+int Work::init(int nh, int nw, int k_, int key_batch, int group) {
     d.set(nh, nw);
     k = k_;
     auto alloc = [&](void **p, size_t bytes) -> int {
@@ -261,27 +261,32 @@ int Work::init(int nh, int nw, int k_, int key_batch) {
     };
     const size_t s1 = (size_t)k * d.hw2 * 64, s2 = (size_t)d.npix * 32, s3 = (size_t)k * d.hw4 * 256;
     const size_t s4 = (size_t)key_batch * d.hw2 * 64;          // batched key encoder
+    const size_t s5 = (size_t)group * d.hw4 * 256;             // batched decoder (k == 1)
     S = s1 > s2 ? s1 : s2;
     S = S > s3 ? S : s3;
     S = S > s4 ? S : s4;
+    S = S > s5 ? S : s5;
+    const int kg = k > group ? k : group;                      // per-(object | frame) buffers of the decoder
     int rc;
     for (float **b : {&A, &B, &C, &D})
         if ((rc = alloc((void **)b, S * sizeof(float)))) return rc;
     splitk_floats = (size_t)32 * 1024 * 1024;      // 128 MB of fp32 slabs; conv falls back to fewer splits
     if ((rc = alloc((void **)&splitk, splitk_floats * sizeof(float)))) return rc;
     if ((rc = alloc((void **)&cbam, (size_t)k * (16 * 1024 + 512 + 3 * d.hw16) * sizeof(float)))) return rc;
-    if ((rc = alloc((void **)&readout, (size_t)k * d.hw16 * 512 * sizeof(float)))) return rc;
-    if ((rc = alloc((void **)&logit4, (size_t)k * d.hw4 * sizeof(float)))) return rc;
+    if ((rc = alloc((void **)&readout, (size_t)kg * d.hw16 * 512 * sizeof(float)))) return rc;
+    if ((rc = alloc((void **)&logit4, (size_t)kg * d.hw4 * sizeof(float)))) return rc;
     if ((rc = alloc((void **)&flogit, (size_t)k * d.npix * sizeof(float)))) return rc;
-    if ((rc = alloc((void **)&agg, (size_t)(k + 1) * d.npix * sizeof(float)))) return rc;
+    if ((rc = alloc((void **)&agg, (size_t)(k + 1) * group * d.npix * sizeof(float)))) return rc;
     if ((rc = alloc((void **)&pooled, (size_t)(k + 1) * 2 * d.hw16 * sizeof(float)))) return rc;
     if ((rc = alloc((void **)&amap, (size_t)(k + 1) * 2 * d.hw16 * sizeof(float)))) return rc;
     if ((rc = alloc((void **)&attn, (size_t)(k + 1) * 2 * d.npix * sizeof(float)))) return rc;
-    if ((rc = alloc((void **)&cand_v, (size_t)16 * d.hw16 * 50 * sizeof(float)))) return rc;
-    if ((rc = alloc((void **)&cand_i, (size_t)16 * d.hw16 * 50 * sizeof(int32_t)))) return rc;
+    // memory-read scratch for Q = group * hw16 queries (a decode group is read in one pass)
+    if ((rc = alloc((void **)&cand_v, (size_t)16 * group * d.hw16 * 50 * sizeof(float)))) return rc;
+    if ((rc = alloc((void **)&cand_i, (size_t)16 * group * d.hw16 * 50 * sizeof(int32_t)))) return rc;
+    if ((rc = alloc((void **)&qk, (size_t)group * d.hw16 * 64 * sizeof(float)))) return rc;
     if ((rc = alloc((void **)&vin, (size_t)k * d.npix * 8 * sizeof(float)))) return rc;
-    if ((rc = alloc((void **)&gmax, (size_t)256 * d.hw16 * sizeof(float)))) return rc;
-    if ((rc = alloc((void **)&tau, (size_t)d.hw16 * sizeof(float)))) return rc;
+    if ((rc = alloc((void **)&gmax, (size_t)256 * group * d.hw16 * sizeof(float)))) return rc;
+    if ((rc = alloc((void **)&tau, (size_t)group * d.hw16 * sizeof(float)))) return rc;
     return STCN_OK;
 }
 void Work::release() {
@@ -473,26 +478,42 @@ int encode_value(const Model &m, Work &w, hipStream_t s, const float *img4, cons
 
 // Decoder (prop_net.py:13-30) on cat[readout, f16_thin] + sigmoid + aggregate_wbg
 int decode(const Model &m, Work &w, hipStream_t s, const float *readout, const float *f16_thin, const float *s8,
-           const float *s4, float *agg, long agg_stride, const float *dthin, const float *cthin) {
+           const float *s4, float *agg, long agg_stride, const float *dthin, const float *cthin, int G, long slot_bs) {
     const Dims &d = w.d;
     const int k = w.k;
-    if (dthin && cthin)
-        RC(resblock_split(m, w, s, "decoder.compress", readout, 512, k, d.h16, d.w16, dthin, cthin, w.C, w.D, w.A, 0));
-    else
+    if (G > 1 && (k != 1 || !dthin || !cthin)) { set_error("decode: frame batches need k == 1 and cached frame parts"); return STCN_E_INVALID; }
+    const int B = G > 1 ? G : k;                 // batch = objects of one frame, or frames of one object
+    const long fbs = G > 1 ? slot_bs : 0;        // per-frame inputs: one per batch element, or broadcast over the objects
+    if (dthin && cthin) {
+        const std::string p = "decoder.compress";
+        const ConvW &cw = m.c(p + ".conv1");
+        const long obs = (long)d.hw16 * cw.cout, xbs = (long)d.hw16 * 512;
+        RC(run_conv(m, w, s, (p + ".downsample#a").c_str(), readout, 512, xbs, nullptr, 0, 0, B, d.h16, d.w16, 1, w.D, 0, dthin, fbs, 0, 0));
+        RC(run_conv(m, w, s, (p + ".conv1#a").c_str(), readout, 512, xbs, nullptr, 0, 0, B, d.h16, d.w16, 1, w.C, 0, cthin, fbs, 1, 1));
+        RC(run_conv(m, w, s, (p + ".conv2").c_str(), w.C, cw.cout, obs, nullptr, 0, 0, B, d.h16, d.w16, 1, w.A, 0, w.D, obs, 0, 0));
+    } else {
         RC(resblock(m, w, s, "decoder.compress", readout, 512, (long)d.hw16 * 512, f16_thin, 512, 0, k, d.h16, d.w16, w.C,
                     w.D, w.A, 0));
-    { Scope sc(w.prof, STCN_K_ELEMWISE, s); upsample2x_add_launch(w.A, s8, w.B, k, d.h16, d.w16, 512, s); }
-    RC(resblock(m, w, s, "decoder.up_16_8.out_conv", w.B, 512, (long)d.hw8 * 512, nullptr, 0, 0, k, d.h8, d.w8, w.C, w.D,
+    }
+    { Scope sc(w.prof, STCN_K_ELEMWISE, s); upsample2x_add_launch(w.A, s8, w.B, B, d.h16, d.w16, 512, s, fbs); }
+    RC(resblock(m, w, s, "decoder.up_16_8.out_conv", w.B, 512, (long)d.hw8 * 512, nullptr, 0, 0, B, d.h8, d.w8, w.C, w.D,
                 w.A, 0));
-    { Scope sc(w.prof, STCN_K_ELEMWISE, s); upsample2x_add_launch(w.A, s4, w.B, k, d.h8, d.w8, 256, s); }
-    RC(resblock(m, w, s, "decoder.up_8_4.out_conv", w.B, 256, (long)d.hw4 * 256, nullptr, 0, 0, k, d.h4, d.w4, w.C, w.D,
+    { Scope sc(w.prof, STCN_K_ELEMWISE, s); upsample2x_add_launch(w.A, s4, w.B, B, d.h8, d.w8, 256, s, fbs); }
+    RC(resblock(m, w, s, "decoder.up_8_4.out_conv", w.B, 256, (long)d.hw4 * 256, nullptr, 0, 0, B, d.h4, d.w4, w.C, w.D,
                 w.A, 0));
     const ConvW &pw = m.c("decoder.pred");
     {
-        Scope sc(w.prof, STCN_K_CONV_N1, s, 2.0 * k * d.hw4 * 9 * 256);
-        conv_n1_launch(w.A, pw.w, pw.bias0, w.logit4, k, d.h4, d.w4, 256, 3, 1, s);
+        Scope sc(w.prof, STCN_K_CONV_N1, s, 2.0 * B * d.hw4 * 9 * 256);
+        conv_n1_launch(w.A, pw.w, pw.bias0, w.logit4, B, d.h4, d.w4, 256, 3, 1, s);
     }
-    { Scope sc(w.prof, STCN_K_ELEMWISE, s); up4_sigmoid_aggregate_launch(w.logit4, k, d.h4, d.w4, agg, agg_stride, s); }
+    {
+        Scope sc(w.prof, STCN_K_ELEMWISE, s);
+        if (G > 1)
+            for (int g = 0; g < G; ++g)
+                up4_sigmoid_aggregate_launch(w.logit4 + (size_t)g * d.hw4, 1, d.h4, d.w4, agg + (size_t)g * 2 * agg_stride, agg_stride, s);
+        else
+            up4_sigmoid_aggregate_launch(w.logit4, k, d.h4, d.w4, agg, agg_stride, s);
+    }
     return STCN_OK;
 }
 
@@ -613,11 +634,16 @@ static int engine_alloc_common(stcn_engine *e) {
     const char *la = getenv("STCN_LOOKAHEAD");
     e->lookahead = la ? atoi(la) : 2;
     if (e->T > e->n_slots) e->lookahead = 0;
+    const char *gb = getenv("STCN_DECODE_BATCH");
+    e->group = gb ? atoi(gb) : 8;
+    if (e->group > e->mem_freq) e->group = e->mem_freq;      // a group ends at the next bank insertion
+    if (e->group < 1 || e->k != 1) e->group = 1;
+    if (e->group > 8) e->group = 8;
     const char *kb = getenv("STCN_KEY_BATCH");
-    e->key_batch = kb ? atoi(kb) : 4;
+    e->key_batch = kb ? atoi(kb) : (e->group > 4 ? e->group : 4);   // a decode group is key-encoded in one pass
     if (e->key_batch < 1) e->key_batch = 1;
     if (e->key_batch > 8) e->key_batch = 8;
-    RC(e->work.init(d.nh, d.nw, e->k, e->lookahead > 0 ? 1 : e->key_batch));
+    RC(e->work.init(d.nh, d.nw, e->k, e->lookahead > 0 ? 1 : e->key_batch, e->group));
     e->work.prof = &e->prof;
     // Look-ahead is only used when no cache slot is ever recycled (T <= slots): the key encoder of the
     // next frames then runs on a side stream concurrently with the memory-read / decoder chain.
@@ -739,23 +765,14 @@ static int clone_state(stcn_engine *e, const stcn_engine *src) {
 // key features of frame ti (cached; inference_core.py:115-124).  enqueue_key() starts the encoder for
 // a missing frame (on the side stream when look-ahead is on); ensure_key() additionally orders the main
 // stream behind it.
-static int enqueue_key(stcn_engine *e, int ti, int step = 0, int stop = 0) {
-    if (e->slot_of[ti] >= 0) return STCN_OK;
-    if (e->n_cached >= e->n_slots) {                         // flush-all policy of the reference
-        std::fill(e->slot_of.begin(), e->slot_of.end(), -1);
-        std::fill(e->vparts_ready.begin(), e->vparts_ready.end(), 0);
-        e->n_cached = 0;
-    }
-    // one encoder pass covers ti and the following uncached frames of the sweep (direction `step`, up to but not
-    // including `stop`), into consecutive cache slots
-    int B = 1;
-    if (step != 0)
-        while (B < e->key_batch && e->n_cached + B < e->n_slots) {
-            const int tn = ti + B * step;
-            if (tn == stop || tn < 0 || tn >= e->T || e->slot_of[tn] >= 0) break;
-            ++B;
-        }
-    const int t_lo = step < 0 ? ti - (B - 1) : ti;           // batch element b = frame t_lo + b (ascending in memory)
+static void flush_key_cache(stcn_engine *e) {                // flush-all policy of the reference
+    std::fill(e->slot_of.begin(), e->slot_of.end(), -1);
+    std::fill(e->vparts_ready.begin(), e->vparts_ready.end(), 0);
+    e->n_cached = 0;
+}
+
+// one encoder pass over the uncached frames t_lo .. t_lo + B - 1 into consecutive cache slots (slot order = frame order)
+static int enqueue_key_batch(stcn_engine *e, int t_lo, int B) {
     const int slot = e->n_cached;
     e->n_cached += B;
     for (int b = 0; b < B; ++b) { e->slot_of[t_lo + b] = slot + b; e->vparts_ready[t_lo + b] = 0; }
@@ -772,6 +789,37 @@ static int enqueue_key(stcn_engine *e, int ti, int step = 0, int stop = 0) {
         RC(encode_key(*e->model, e->work, e->stream, img, ko, B, (long)e->slot_floats));
     }
     e->stats.key_miss += B;
+    return STCN_OK;
+}
+
+// frame ti, together with the following uncached frames of the sweep (direction `step`, up to but not including `stop`)
+static int enqueue_key(stcn_engine *e, int ti, int step = 0, int stop = 0) {
+    if (e->slot_of[ti] >= 0) return STCN_OK;
+    if (e->n_cached >= e->n_slots) flush_key_cache(e);
+    int B = 1;
+    if (step != 0)
+        while (B < e->key_batch && e->n_cached + B < e->n_slots) {
+            const int tn = ti + B * step;
+            if (tn == stop || tn < 0 || tn >= e->T || e->slot_of[tn] >= 0) break;
+            ++B;
+        }
+    return enqueue_key_batch(e, step < 0 ? ti - (B - 1) : ti, B);
+}
+
+// the frames t_lo .. t_lo + G - 1 of one decode group: every maximal run of uncached frames becomes one encoder pass,
+// so a group that is encoded together sits in consecutive slots in frame order, whatever the sweep direction
+static int enqueue_group(stcn_engine *e, int t_lo, int G) {
+    int missing = 0;
+    for (int b = 0; b < G; ++b) missing += e->slot_of[t_lo + b] < 0;
+    if (!missing) return STCN_OK;
+    if (e->n_cached + missing > e->n_slots) { flush_key_cache(e); }   // earlier work is already enqueued on this stream
+    for (int b = 0; b < G;) {
+        if (e->slot_of[t_lo + b] >= 0) { ++b; continue; }
+        int n = 1;
+        while (b + n < G && n < e->key_batch && e->slot_of[t_lo + b + n] < 0) ++n;
+        RC(enqueue_key_batch(e, t_lo + b, n));
+        b += n;
+    }
     return STCN_OK;
 }
 
@@ -823,7 +871,10 @@ static void dbg_sum(stcn_engine *e, const char *tag, int ti, const float *p, siz
     (void)e;
 }
 
-// do_pass (inference_core.py:126-191)
+// do_pass (inference_core.py:126-191).  A frame's segmentation depends on its own key features and on the memory bank
+// only, and the bank changes only when a frame is inserted (every mem_freq-th): the frames up to and including the
+// next insertion are independent of each other, so (for k == 1) their memory reads and decoder passes run as ONE batch
+// of up to `group` frames - 5x the rows per implicit GEMM at mem_freq = 5, 1/5 of the launches.
 static int do_pass(stcn_engine *e, int idx, bool forward) {
     const Dims &d = e->d;
     const int T = e->T, k = e->k;
@@ -837,50 +888,101 @@ static int do_pass(stcn_engine *e, int idx, bool forward) {
     const int step = forward ? 1 : -1, end = closest - step;
     const bool fuse = closest != T && closest != -1;
     const long prs = (long)T * d.npix;                      // prob row stride
+    const long agg_fs = (long)(k + 1) * d.npix;             // floats per frame in w.agg
     Work &w = e->work;
-    for (int ti = idx + step; ti != closest; ti += step) {
-        RC(enqueue_key(e, ti, step, closest));
-        for (int a = 1, tj = ti + step; a <= e->lookahead && tj != closest; ++a, tj += step) RC(enqueue_key(e, tj, step, closest));
-        SlotPtrs kf;
-        RC(ensure_key(e, ti, &kf));
-        {
-            const int N = m_front * d.hw16;
-            Scope sc(&e->prof, STCN_K_MEMREAD, e->stream, 2.0 * N * d.hw16 * 64 + 2.0 * k * d.hw16 * 50 * 512);
-            memory_read_launch(e->bank_k, e->bank_msq, kf.k16, N, d.hw16, e->bank_v, (long)e->bank_cap * d.hw16 * 512, k,
-                               w.readout, (long)d.hw16 * 512, nullptr, nullptr, MemReadScratch{w.cand_v, w.cand_i, w.gmax, w.tau}, e->stream);
-        }
-        dbg_sum(e, "k16", ti, kf.k16, (size_t)d.hw16 * 64);
-        dbg_sum(e, "readout", ti, w.readout, (size_t)k * d.hw16 * 512);
-        RC(decode(*e->model, w, e->stream, w.readout, kf.f16_thin, kf.s8, kf.s4, w.agg, d.npix, kf.dthin, kf.cthin));
-        dbg_sum(e, "agg", ti, w.agg, (size_t)(k + 1) * d.npix);
-        if (ti != end && std::abs(ti - last_ti) >= e->mem_freq) {
-            RC(bank_insert(e, m_front, ti, kf, w.agg + d.npix, d.npix));
-            ++m_front;
-            last_ti = ti;
-        }
-        float *dst = e->prob + (size_t)ti * d.npix;
-        if (fuse) {
-            // fuse_one_frame (inference_core.py:193-207): tc = closest, tr = idx
-            const float nc = (float)std::abs(closest - ti) / (float)std::abs(closest - idx);
-            const float nr = (float)std::abs(idx - ti) / (float)std::abs(closest - idx);
-            const int cs = e->n_certain - 1;               // key of the current interaction
-            {
-                Scope sc(&e->prof, STCN_K_OTHER, e->stream, 2.0 * d.hw16 * d.hw16 * 64);
-                attention_read_launch(e->bank_k + (size_t)cs * d.hw16 * 64, e->bank_msq + (size_t)cs * d.hw16, kf.k16, e->pos,
-                                      e->neg, k + 1, d.h16, d.w16, w.pooled, w.amap, w.attn, AttnScratch{w.gmax, w.tau, w.cand_v}, e->stream);
+    int ti = idx + step;
+    while (ti != closest) {
+        // ---- the group: ti and the following frames up to and including the next bank insertion
+        int G = 1;
+        const int gmax = k == 1 ? e->group : 1;
+        auto inserts = [&](int t) { return t != end && std::abs(t - last_ti) >= e->mem_freq; };
+        while (G < gmax && !inserts(ti + (G - 1) * step) && ti + G * step != closest) ++G;
+        std::vector<SlotPtrs> kf(G);
+        const int t_lo = forward ? ti : ti - (G - 1);
+        if (gmax > 1) {
+            // keys by group: this group, then (look-ahead) the next one on the side stream while this one decodes
+            RC(enqueue_group(e, t_lo, G));
+            const int t1 = ti + G * step;
+            if (e->lookahead > 0 && t1 != closest) {
+                const int tl = ti + (G - 1) * step, last1 = inserts(tl) ? tl : last_ti;
+                int G1 = 1;
+                while (G1 < gmax && !(t1 + (G1 - 1) * step != end && std::abs(t1 + (G1 - 1) * step - last1) >= e->mem_freq) &&
+                       t1 + G1 * step != closest) ++G1;
+                RC(enqueue_group(e, forward ? t1 : t1 - (G1 - 1), G1));
             }
-            for (int o = 1; o <= k; ++o)
-                RC(fusion_logit(*e->model, w, e->stream, e->images4 + (size_t)ti * d.npix * 4, dst + (size_t)o * prs,
-                                w.agg + (size_t)o * d.npix, w.attn + (size_t)o * 2 * d.npix, nc, nr,
-                                w.flogit + (size_t)(o - 1) * d.npix));
-            Scope sc(&e->prof, STCN_K_ELEMWISE, e->stream);
-            sigmoid_aggregate_launch(w.flogit, k, d.npix, dst, prs, e->stream);
-            e->stats.fused++;
         } else {
-            Scope sc(&e->prof, STCN_K_ELEMWISE, e->stream);
-            copy_rows_launch(w.agg, d.npix, dst, prs, k + 1, d.npix, e->stream);
+            RC(enqueue_key(e, ti, step, closest));
+            for (int a = 1, tj = ti + step; a <= e->lookahead && tj != closest; ++a, tj += step) RC(enqueue_key(e, tj, step, closest));
         }
-        e->stats.frames++;
+        for (int g = 0; g < G; ++g) RC(ensure_key(e, ti + g * step, &kf[g]));
+        // one batched pass needs the group's cache slots in one arithmetic progression (frame order = slot order)
+        bool batched = G > 1;
+        for (int b = 1; b < G && batched; ++b) batched = e->slot_of[t_lo + b] == e->slot_of[t_lo] + b;
+        const int N = m_front * d.hw16;
+        auto read = [&](const SlotPtrs &f, float *readout) {
+            Scope sc(&e->prof, STCN_K_MEMREAD, e->stream, 2.0 * N * d.hw16 * 64 + 2.0 * k * d.hw16 * 50 * 512);
+            memory_read_launch(e->bank_k, e->bank_msq, f.k16, N, d.hw16, e->bank_v, (long)e->bank_cap * d.hw16 * 512, k, readout,
+                               (long)d.hw16 * 512, nullptr, nullptr, MemReadScratch{w.cand_v, w.cand_i, w.gmax, w.tau}, e->stream);
+        };
+        // agg of the frame at sweep position g lives at w.agg + pos(g) * agg_fs
+        auto pos = [&](int g) { return batched ? (ti + g * step) - t_lo : 0; };
+        if (batched) {
+            const SlotPtrs &f0 = kf[forward ? 0 : G - 1];      // slot of frame t_lo
+            {   // the group's queries, contiguous: one read of the bank serves G * hw16 queries
+                Scope sc(&e->prof, STCN_K_ELEMWISE, e->stream);
+                copy_rows_launch(f0.k16, (long)e->slot_floats, w.qk, (long)d.hw16 * 64, G, (long)d.hw16 * 64, e->stream);
+            }
+            {
+                Scope sc(&e->prof, STCN_K_MEMREAD, e->stream, G * (2.0 * N * d.hw16 * 64 + 2.0 * d.hw16 * 50 * 512));
+                memory_read_launch(e->bank_k, e->bank_msq, w.qk, N, G * d.hw16, e->bank_v, (long)e->bank_cap * d.hw16 * 512, 1,
+                                   w.readout, (long)G * d.hw16 * 512, nullptr, nullptr, MemReadScratch{w.cand_v, w.cand_i, w.gmax, w.tau},
+                                   e->stream);
+            }
+            RC(decode(*e->model, w, e->stream, w.readout, f0.f16_thin, f0.s8, f0.s4, w.agg, d.npix, f0.dthin, f0.cthin, G,
+                      (long)e->slot_floats));
+        }
+        // ---- per frame, in sweep order: (unbatched: read + decode,) bank insertion, fusion / output
+        for (int g = 0; g < G; ++g) {
+            const int t = ti + g * step;
+            const SlotPtrs &f = kf[g];
+            float *agg = w.agg + (size_t)pos(g) * agg_fs;
+            if (!batched) {
+                read(f, w.readout);
+                dbg_sum(e, "k16", t, f.k16, (size_t)d.hw16 * 64);
+                dbg_sum(e, "readout", t, w.readout, (size_t)k * d.hw16 * 512);
+                RC(decode(*e->model, w, e->stream, w.readout, f.f16_thin, f.s8, f.s4, agg, d.npix, f.dthin, f.cthin));
+            }
+            dbg_sum(e, "agg", t, agg, (size_t)(k + 1) * d.npix);
+            if (inserts(t)) {
+                RC(bank_insert(e, m_front, t, f, agg + d.npix, d.npix));
+                ++m_front;
+                last_ti = t;
+            }
+            float *dst = e->prob + (size_t)t * d.npix;
+            if (fuse) {
+                // fuse_one_frame (inference_core.py:193-207): tc = closest, tr = idx
+                const float nc = (float)std::abs(closest - t) / (float)std::abs(closest - idx);
+                const float nr = (float)std::abs(idx - t) / (float)std::abs(closest - idx);
+                const int cs = e->n_certain - 1;               // key of the current interaction
+                {
+                    Scope sc(&e->prof, STCN_K_OTHER, e->stream, 2.0 * d.hw16 * d.hw16 * 64);
+                    attention_read_launch(e->bank_k + (size_t)cs * d.hw16 * 64, e->bank_msq + (size_t)cs * d.hw16, f.k16, e->pos,
+                                          e->neg, k + 1, d.h16, d.w16, w.pooled, w.amap, w.attn, AttnScratch{w.gmax, w.tau, w.cand_v}, e->stream);
+                }
+                for (int o = 1; o <= k; ++o)
+                    RC(fusion_logit(*e->model, w, e->stream, e->images4 + (size_t)t * d.npix * 4, dst + (size_t)o * prs,
+                                    agg + (size_t)o * d.npix, w.attn + (size_t)o * 2 * d.npix, nc, nr,
+                                    w.flogit + (size_t)(o - 1) * d.npix));
+                Scope sc(&e->prof, STCN_K_ELEMWISE, e->stream);
+                sigmoid_aggregate_launch(w.flogit, k, d.npix, dst, prs, e->stream);
+                e->stats.fused++;
+            } else {
+                Scope sc(&e->prof, STCN_K_ELEMWISE, e->stream);
+                copy_rows_launch(agg, d.npix, dst, prs, k + 1, d.npix, e->stream);
+            }
+            e->stats.frames++;
+        }
+        ti += G * step;
     }
     (forward ? e->stats.bank_fwd : e->stats.bank_bwd) = m_front;
     return STCN_OK;

@@ -90,10 +90,11 @@ struct Work {
     float *pooled = nullptr, *amap = nullptr, *attn = nullptr;   // attention read
     float *cand_v = nullptr; int32_t *cand_i = nullptr;          // memory-read chunk winners
     float *gmax = nullptr, *tau = nullptr;                       // memory-read group maxima / thresholds
+    float *qk = nullptr;                // [group][hw16][64] queries of a decode group
     float *vin = nullptr;               // value-encoder packed input [k][npix][8]
     Prof *prof = nullptr;
     std::vector<void *> allocs;
-    int init(int nh, int nw, int k, int key_batch = 1);
+    int init(int nh, int nw, int k, int key_batch = 1, int group = 1);   // group: frames decoded per pass (k == 1)
     void release();
 };
 
@@ -110,9 +111,11 @@ int encode_value(const Model &m, Work &w, hipStream_t s, const float *img4, cons
                  const float *vc = nullptr);
 int value_frame_parts(const Model &m, Work &w, hipStream_t s, const float *f16, float *vd, float *vc);
 // dthin / cthin: cached frame-only halves of decoder.compress (nullptr: full two-source convs)
+// G > 1 (k == 1 only): G frames at once - readout [G][hw16][512], agg [G][2][npix], the per-frame inputs of frame g at
+// <ptr> + g * slot_bs (consecutive key-cache slots)
 int decode(const Model &m, Work &w, hipStream_t s, const float *readout, const float *f16_thin,
            const float *s8, const float *s4, float *agg, long agg_stride, const float *dthin = nullptr,
-           const float *cthin = nullptr);
+           const float *cthin = nullptr, int G = 1, long slot_bs = 0);
 int fusion_logit(const Model &m, Work &w, hipStream_t s, const float *img4, const float *prev,
                  const float *curr, const float *attn2, float nc, float nr, float *logit);
 
@@ -149,6 +152,7 @@ struct stcn_engine {
     std::vector<char> key_pending;       // per frame: main stream has not yet waited on key_ready
     int lookahead = 0;
     int key_batch = 1;                   // frames per key-encoder pass (env STCN_KEY_BATCH)
+    int group = 1;                       // frames per memory-read + decoder pass (env STCN_DECODE_BATCH, k == 1)
     stcn::Prof prof;
     stcn_stats stats{};
     std::vector<void *> allocs;

@@ -59,9 +59,9 @@ void pack_image_launch(const float *img_chw, float *out, int H, int W, int nh, i
 // value-encoder input [k,nh,nw,8] = (rgb from NHWC4 image, mask_i, sum_{j!=i} mask_j, 0,0,0)
 void pack_value_input_launch(const float *img4, const float *masks, long mask_stride, int k, int npix,
                              float *out, hipStream_t s);
-// u[b] = skip (broadcast over b) + bilinear_up2x(x[b]); x [B,h,w,C] -> u [B,2h,2w,C]
+// u[b] = skip[b * skip_bs] (skip_bs 0: broadcast over b) + bilinear_up2x(x[b]); x [B,h,w,C] -> u [B,2h,2w,C]
 void upsample2x_add_launch(const float *x, const float *skip, float *u, int B, int h, int w, int C,
-                           hipStream_t s);
+                           hipStream_t s, long skip_bs = 0);
 // logit4 [k,h4*w4] -> bilinear x4 -> sigmoid -> aggregate_wbg -> agg [k+1][nh*nw] (row stride agg_stride)
 void up4_sigmoid_aggregate_launch(const float *logit4, int k, int h4, int w4, float *agg,
                                   long agg_stride, hipStream_t s);
