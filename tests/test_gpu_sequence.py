@@ -195,15 +195,18 @@ def test_long_clip_exercises_cache_flush_policy(nets, weights):
 
 @pytest.mark.parametrize("lookahead", ["0", "2"])
 def test_key_batching_does_not_change_results(nets, monkeypatch, lookahead):
-    """The key encoder runs over up to STCN_KEY_BATCH frames per pass (forward sweeps ascending, backward sweeps
-    descending, stopping at interacted frames); per-frame results only see a different M of the same GEMMs."""
+    """The key encoder runs over up to STCN_KEY_BATCH frames per pass and the memory read + decoder over the frames up to
+    the next bank insertion (STCN_DECODE_BATCH), forward and backward sweeps, stopping at interacted frames; per-frame
+    results only see a different M of the same GEMMs."""
     T, H, W = 15, 112, 144
     img = synth.synthetic_clip(T, H, W, seed=4)
     msk = synth.synthetic_mask(T, H, W, 1, seed=5)
     monkeypatch.setenv("STCN_LOOKAHEAD", lookahead)
     res = {}
-    for kb in ("1", "3", "4", "8"):
-        monkeypatch.setenv("STCN_KEY_BATCH", kb)
+    for kb in ("1", "3", "4", "8", "g1", "g2"):
+        # kb: frames per key-encoder pass; g<n>: frames per memory-read + decoder pass (default min(mem_freq, 8) = 3 here)
+        monkeypatch.setenv("STCN_KEY_BATCH", "4" if kb[0] == "g" else kb)
+        monkeypatch.setenv("STCN_DECODE_BATCH", kb[1:] if kb[0] == "g" else "8")
         core = make_core(nets)(img, 1, 3)
         m1 = core.interact(msk[:, 9], 9).copy()            # backward sweep 8..0 and forward sweep 10..14
         s = core.stats()
@@ -211,7 +214,8 @@ def test_key_batching_does_not_change_results(nets, monkeypatch, lookahead):
         m2 = core.interact(msk[:, 4], 4).copy()            # all keys cached, fusion between 4 and 9
         assert core.stats()["key_miss"] == 0
         res[kb] = (m1, m2, core.prob.clone())
-    for kb in ("3", "4", "8"):
+    res["1"] = res["g1"]                                   # reference point: no batching of the decode at all
+    for kb in ("3", "4", "8", "g2"):
         assert iou(res[kb][0], res["1"][0]) >= 1 - 1e-3 and iou(res[kb][1], res["1"][1]) >= 1 - 1e-3
         assert (res[kb][2] - res["1"][2]).abs().max().item() < 2e-3
 
