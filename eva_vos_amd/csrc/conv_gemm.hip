@@ -404,9 +404,9 @@ static inline bool smallc_variant(const ConvP &p) {
 // Cost model in K-tile times of one 64x64 workgroup (~0.45 us): the chip runs "rounds" of 256 workgroups (one per CU;
 // co-resident workgroups of a CU share its MFMA pipes, so only the count per CU matters), a workgroup costs its K tiles
 // plus ~3 for prologue / epilogue.  Candidates:
-//   * tile 64x64 (128x32 for Cout <= 32); 128x128 tiles (each wave 2x2 accumulator blocks: half the LDS reads and staging
-//     per MFMA, +8 % on a GEMM that fills the chip evenly) are opt-in (STCN_CONV_BIG=1 lets the model choose, 2 forces
-//     them for deep-K GEMMs): once the tails are balanced they win on none of this path's shapes by more than 3 %;
+//   * tile 64x64 (128x32 for Cout <= 32) or, for deep-K GEMMs, 128x128 (each wave 2x2 accumulator blocks: half the
+//     LDS reads and staging per MFMA, +8 % on a GEMM that fills the chip evenly; +4 % on the 5-frame decoder batches at
+//     1/8 and 1/16 scale).  STCN_CONV_BIG: 0 never, 1 the model chooses (default), 2 always for deep-K GEMMs;
 //   * plain split-K s (slabs + conv_reduce_kernel) when the tiles do not fill the chip;
 //   * tail balancing when they fill it more than once: the whole rounds run unsplit and only the tiles of the ragged
 //     last round are cut into K pieces (1620 tiles = 6 rounds + 84 tiles x 3 pieces instead of 7 rounds).
@@ -450,7 +450,7 @@ static Plan plan_variant(const ConvP &p, bool big, int force_splitk, size_t ws_f
 }
 
 void conv_plan(ConvP &p, int force_splitk, size_t ws_floats) {
-    static const int big_mode = [] { const char *e = getenv("STCN_CONV_BIG"); return e ? atoi(e) : 0; }();
+    static const int big_mode = [] { const char *e = getenv("STCN_CONV_BIG"); return e ? atoi(e) : 1; }();
     Plan pl = plan_variant(p, false, force_splitk, ws_floats);
     const bool big_ok = big_mode != 0 && !(p.mode & 1) && !narrow_variant(p) && !smallc_variant(p) && p.N >= 256 && p.Kp >= 2304;
     if (big_ok) {
