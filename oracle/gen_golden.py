@@ -18,7 +18,9 @@ import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [os.path.join(ROOT, "oracle", "_stub"), "/root/reference", ROOT]
+# the reference first, WITHOUT the repo root on the path: the reference's `mivos` has no __init__.py (namespace package)
+# and the repo's drop-in `mivos/` alias package would win the import otherwise
+sys.path[:] = [os.path.join(ROOT, "oracle", "_stub"), "/root/reference"] + [p for p in sys.path if os.path.abspath(p or ".") != ROOT]
 torch.set_grad_enabled(False)
 
 import mivos.model.propagation.mod_resnet as _mr  # noqa: E402  (reference)
@@ -31,6 +33,8 @@ with contextlib.redirect_stdout(io.StringIO()):
     from mivos.model.aggregate import aggregate_wbg  # noqa: E402
     from mivos.tensor_util import pad_divide_by  # noqa: E402
 
+assert RefCore.__module__ == "mivos.inference_core" and "/root/reference" in sys.modules["mivos.inference_core"].__file__
+sys.path.append(ROOT)
 from eva_vos_amd import synth  # noqa: E402
 from eva_vos_amd.params import FusionNet, PropagationNetwork  # noqa: E402
 from oracle import stcn_oracle as O  # noqa: E402
@@ -182,6 +186,8 @@ SEQ_CASES = {
     "seqA": dict(H=128, W=160, k=1, T=12, mem_freq=5, script=[(0, 0), (8, 8), (7, 8)]),
     "seqB": dict(H=100, W=150, k=1, T=8, mem_freq=3, script=[(3, 3), (6, 6)]),
     "seqC": dict(H=128, W=160, k=3, T=8, mem_freq=2, script=[(0, 0), (5, 5)]),
+    # config-3-shaped: 5 objects, every frame enters the bank, ragged size (pads 4/4 and 3/3)
+    "seqD": dict(H=120, W=170, k=5, T=7, mem_freq=1, script=[(0, 0), (4, 4)]),
 }
 STAGE_CASES = {
     "stA": dict(H=128, W=160, k=1),
@@ -192,6 +198,14 @@ STAGE_CASES = {
 def main():
     os.makedirs(GOLD, exist_ok=True)
     net, fus, psd, fsd = load_reference()
+    only = [a.split("=")[1] for a in sys.argv if a.startswith("--only=")]      # e.g. --only=seqD: just that fixture
+    if only:
+        for tag in only:
+            out = {}
+            rep = seq_case(tag, net=net, fus=fus, psd=psd, fsd=fsd, out=out, **SEQ_CASES[tag])
+            np.savez_compressed(os.path.join(GOLD, f"{tag}.npz"), **out)
+            print(tag, rep)
+        return
     for tag, c in STAGE_CASES.items():
         out = {}
         rep = stage_case(tag, c["H"], c["W"], c["k"], net, psd, out)

@@ -19,7 +19,7 @@ def make_core(nets):
     return lambda img, k, mf: InferenceCore(nets[0], nets[1], img, k, mem_freq=mf)
 
 
-@pytest.mark.parametrize("tag", ["seqA", "seqB", "seqC"])
+@pytest.mark.parametrize("tag", ["seqA", "seqB", "seqC", "seqD"])
 def test_sequences_match_reference_goldens(tag, nets):
     g = load_golden(tag)
     outs = run_sequence(make_core(nets), tag, g)

@@ -107,7 +107,7 @@ def check_sequence_against_golden(outs, tag, g, prob_atol, min_iou=1 - 1e-3):
         assert np.quantile(d, 0.999) < 0.05, (tag, r, float(np.quantile(d, 0.999)))
 
 
-@pytest.mark.parametrize("tag", ["seqA", "seqB", "seqC"])
+@pytest.mark.parametrize("tag", ["seqA", "seqB", "seqC", "seqD"])
 def test_sequence_matches_reference(tag, weights):
     g = load_golden(tag)
     outs = run_sequence(lambda img, k, mf: O.OracleCore(weights[0], weights[1], img, k, mem_freq=mf), tag, g)
