@@ -50,7 +50,8 @@ def parse():
     ap.add_argument("--streams", type=int, default=3, help="videos in flight per GPU (one host thread + HIP stream each)")
     ap.add_argument("--no-f16x3-leg", dest="f16x3_leg", action="store_false",
                     help="skip the extra (non-headline) f16x3 split-precision leg")
-    ap.add_argument("--r2", action="store_true", help="also time a second interaction (cached keys + fusion)")
+    ap.add_argument("--no-r2", dest="r2", action="store_false",
+                    help="skip the extra R2 number (a second interaction: cached keys + fusion; reported, not the headline)")
     return ap.parse_args()
 
 
