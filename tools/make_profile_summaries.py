@@ -54,6 +54,24 @@ lines += ["", f"conv_gemm_kernel (all variants): {conv_calls} launches, {conv_ns
           f"one video in flight: {s1['value']:.1f} frames/s."]
 open(os.path.join(DST, f"{tag}_bench_streams1_kernel_stats.md"), "w").write("\n".join(lines) + "\n")
 
+# ---- trace of the default command (3 videos in flight + the solo roofline leg in one process)
+td = os.path.join(SRC, "trace_default", "r_kernel_stats.csv")
+if os.path.exists(td):
+    st = list(csv.DictReader(open(td)))
+    shutil.copy(td, os.path.join(DST, f"{tag}_bench_default_kernel_stats.csv"))
+    cv = [r for r in st if "conv_gemm_kernel" in r["Name"]]
+    calls = sum(int(r["Calls"]) for r in cv)
+    ns = sum(float(r["TotalDurationNs"]) for r in cv)
+    bd = last_json(os.path.join(SRC, "trace_default.log"))
+    open(os.path.join(DST, f"{tag}_bench_default_kernel_stats.md"), "w").write(
+        f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --cpu-frames 0 --no-f16x3-leg --no-r2 ({tag})\n\n"
+        f"The default command: {bd['config']['streams_per_gpu']} videos in flight in the timed region ({bd['value']:.1f} frames/s under the "
+        f"profiler) plus the solo roofline leg, in one process.\nconv_gemm_kernel, all variants: {calls} launches, {ns / 1e6:.1f} ms, "
+        f"average {ns / calls / 1e3:.2f} us per launch.  Kernels of concurrent videos overlap here, so this average is NOT the "
+        f"kernel's solo duration: while three conv kernels share the chip each one takes longer.  The roofline uses solo launches "
+        f"(roofline leg avg {bd['roofline']['avg_launch_ms'] * 1e3:.2f} us = the `--streams 1` trace in "
+        f"`{tag}_bench_streams1_kernel_stats.md`).\n\nFull table: `{tag}_bench_default_kernel_stats.csv`.\n")
+
 # ---- PMC traffic (FETCH_SIZE x2 + WRITE_SIZE, KB units, separate passes)
 def per_kernel(path, counter):
     agg = collections.defaultdict(list)
