@@ -10,7 +10,8 @@ the writer ``util/fq_dataset.py:50-91`` (224x224 nearest-resized masks as PNG + 
 * samples are assigned to ranks with an LPT schedule over their frame counts instead of ``--min-idx/--max-idx``;
   propagation has no collective; ONE gather of fixed-width rows at the end (RCCL over xGMI), rank 0 writes the CSV;
 * a decoded clip is cached per video and reused for all its objects (the reference re-decodes it per object);
-* J is computed on the GPU from the engine's mask tensor (``stcn_metrics_jf_counts``), only counts cross PCIe.
+* J is computed on the GPU from the engine's mask tensor (``stcn_metrics_jf_counts``), only counts cross PCIe;
+* the 224x224 PNG states are encoded and written by host threads while the GPU propagates the next round.
 
 Usage:  python -m eva_vos_amd.fq_driver --root data/MOSE --imset data/MOSE/ImageSets/subset_train_4.txt --out FQ_DB
         (multi-GPU: python -m torch.distributed.run --nproc-per-node N -m eva_vos_amd.fq_driver ...)
@@ -175,12 +176,22 @@ def oracle_rounds(processor, sample, rounds: int = 8):
 
 
 # ------------------------------------------------------------------------------------------------ output
-def save_state_masks(gen: torch.Tensor, out_dir: str):
-    """224x224 nearest-neighbour PNGs like util/fq_dataset.py:64-84 (mask_to_224)."""
-    os.makedirs(out_dir, exist_ok=True)
+def save_state_masks(gen: torch.Tensor, out_dir: str, pool=None):
+    """224x224 nearest-neighbour PNGs like util/fq_dataset.py:64-84 (mask_to_224).  The resize runs on the device; with
+    `pool` (a ThreadPoolExecutor) the PNG encoding + file writes of the state happen on host threads while the GPU
+    propagates the next round (zlib and file I/O release the GIL); returns the future, or None when done inline."""
     small = torch.nn.functional.interpolate(gen[:, None].float(), size=(224, 224), mode="nearest")[:, 0]
-    for t, m in enumerate((small * 255).to(torch.uint8).cpu().numpy()):
-        Image.fromarray(m).save(os.path.join(out_dir, f"{t:05d}.png"))
+    frames = (small * 255).to(torch.uint8).cpu().numpy()
+
+    def write():
+        os.makedirs(out_dir, exist_ok=True)
+        for t, m in enumerate(frames):
+            Image.fromarray(m).save(os.path.join(out_dir, f"{t:05d}.png"))
+
+    if pool is None:
+        write()
+        return None
+    return pool.submit(write)
 
 
 def run(root: str, imset: str, out: str, prop_net, fuse_net, rounds: int = 8, save_masks: bool = True,
@@ -197,6 +208,9 @@ def run(root: str, imset: str, out: str, prop_net, fuse_net, rounds: int = 8, sa
     mine = sorted(shard.lpt_assign([s[2] for s in ds.samples], world)[rank])     # adjacent objects share a decode
     width = 4 + t_max
     rows = []
+    from concurrent.futures import ThreadPoolExecutor
+    writers = ThreadPoolExecutor(4) if save_masks else None
+    pending = []
     for i, sample in prefetched(ds, mine, device):
         proc = InferenceCore(prop_net, fuse_net, sample["rgb"], 1)
         states, gens = oracle_rounds(proc, sample, rounds)
@@ -209,9 +223,13 @@ def run(root: str, imset: str, out: str, prop_net, fuse_net, rounds: int = 8, sa
             row[4:4 + len(q)] = q
             rows.append(row)
             if save_masks:
-                save_state_masks(gen, os.path.join(out, "Annotations", "224", f"{sample['name']}_round_{sid}"))
+                pending.append(save_state_masks(gen, os.path.join(out, "Annotations", "224", f"{sample['name']}_round_{sid}"), writers))
             sid += 1
         del proc
+    for f in pending:
+        f.result()                                         # surface write errors; all PNGs are on disk before the CSV
+    if writers is not None:
+        writers.shutdown()
     allrows = shard.gather_rows(np.stack(rows) if rows else np.zeros((0, width), np.float32), width)
     if rank == 0:
         os.makedirs(out, exist_ok=True)
