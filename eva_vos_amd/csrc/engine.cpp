@@ -310,8 +310,14 @@ int run_conv(const Model &m, Work &w, hipStream_t s, const char *name, const flo
     p.OW = (W + 2 * p.pad - cw.kw) / stride + 1;
     p.Cin = cw.cin_p;
     p.M = B * p.OH * p.OW; p.N = cw.cout; p.K = cw.K; p.Kp = cw.Kp;
-    p.x0_bytes = (unsigned)(((bs0 ? (long)B * bs0 : (long)H * W * c0)) * 4);
-    p.x1_bytes = x1 ? (unsigned)(((bs1 ? (long)B * bs1 : (long)H * W * c1)) * 4) : 0u;
+    // the kernels address operands with 32-bit byte offsets (buffer loads): refuse anything beyond 2 GiB per operand
+    const long x0b = (bs0 ? (long)B * bs0 : (long)H * W * c0) * 4, x1b = x1 ? (bs1 ? (long)B * bs1 : (long)H * W * c1) * 4 : 0;
+    if (x0b >= (1L << 31) || x1b >= (1L << 31) || (long)cw.cout * cw.Kp * 4 >= (1L << 31)) {
+        set_error("conv '%s': operand of %ld bytes exceeds the 2 GiB the kernels can address (B=%d, %dx%d)", name, x0b > x1b ? x0b : x1b, B, H, W);
+        return STCN_E_INVALID;
+    }
+    p.x0_bytes = (unsigned)x0b;
+    p.x1_bytes = (unsigned)x1b;
     p.w_bytes = (unsigned)((long)cw.cout * cw.Kp * 4);
     if (x1 && ((cw.cin_p % 32) || (c0 % 32) || cw.kh * cw.kw > 32)) { set_error("conv '%s': two-source input needs 32-aligned channel splits", name); return STCN_E_INVALID; }
     p.w = cw.w; p.w_hi = cw.w_hi; p.w_lo = cw.w_lo; p.oscale = cw.oscale;
