@@ -67,7 +67,7 @@ def _upper_bound_frame(processor, gt, gt_thw, frames, metric):
         if f in frames:
             continue
         p = copy.deepcopy(processor)
-        p.interact(gt[f][None], f)
+        p.interact(gt[f][None], f, download=False)
         mu, _, _ = frame_quality(p, gt_thw, frames + [f], metric)
         if mu >= best:
             best, best_f = mu, f
@@ -92,7 +92,7 @@ def run_policy(policy: str, processor, sample, rounds: int, metric: str = "j_and
         if r >= T or (q is not None and _exhausted(q, frames, T)):
             continue
         f = frames[r - 1]
-        processor.interact(gt[f][None], f)
+        processor.interact(gt[f][None], f, download=False)
         mu, gen, q = frame_quality(processor, gt_thw, frames, metric)
         mus.append(mu)
         per_round.append(q.copy())

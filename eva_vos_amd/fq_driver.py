@@ -166,7 +166,7 @@ def oracle_rounds(processor, sample, rounds: int = 8):
         if quality is not None and not (set(range(T)) - set(np.where(quality == NO_OBJECT)[0].tolist()) - set(frames)):
             continue
         f = frames[r - 1]
-        processor.interact(gt[f][None], f)                         # [1,1,H,W] mask of the annotated frame
+        processor.interact(gt[f][None], f, download=False)         # [1,1,H,W] mask of the annotated frame
         quality, gen = per_frame_j(processor, gt_thw, frames[:r])
         worst = int(np.argmin(quality))
         frames.append(worst)

@@ -104,8 +104,12 @@ class InferenceCore:
         self.interacted = set()
 
     # ------------------------------------------------------------------------------------------
-    def interact(self, mask, idx, scribble=False):
-        """Interact -> propagate -> fuse; returns np.uint8 [t,h,w] (reference inference_core.py:209-259)."""
+    def interact(self, mask, idx, scribble=False, download=True):
+        """Interact -> propagate -> fuse; returns np.uint8 [t,h,w] (reference inference_core.py:209-259).
+
+        ``download=False`` (not in the reference) skips the device-to-host copy of the masks and returns None: callers
+        that evaluate on the device (``processor.masks`` / ``processor.prob``, e.g. eva_vos_amd.eval_driver) save the
+        27 MB transfer + host sync per annotation round."""
         idx = int(idx)
         mask = mask.detach().to(self.device, torch.float32).contiguous()
         if mask.dim() != 4 or mask.shape[1] != 1 or tuple(mask.shape[-2:]) != (self.h, self.w):
@@ -114,6 +118,8 @@ class InferenceCore:
             _lib.check(_lib.lib().stcn_interact(self._engine, mask.data_ptr(), int(mask.shape[0]), idx,
                                                 1 if scribble else 0), "stcn_interact")
             self.interacted.add(idx)
+            if not download:
+                return None
             lw, uw, lh, uh = self.pad
             out = self.masks[:, 0, lh:self.nh - uh, lw:self.nw - uw]
             self.np_masks = out.cpu().numpy().astype(np.uint8)     # D2H sync, as the reference's .cpu()
