@@ -220,6 +220,25 @@ def test_key_batching_does_not_change_results(nets, monkeypatch, lookahead):
         assert (res[kb][2] - res["1"][2]).abs().max().item() < 2e-3
 
 
+@pytest.mark.parametrize("T,mem_freq,idx", [(30, 12, 17), (9, 50, 0), (3, 5, 1), (2, 1, 0)])
+def test_decode_groups_with_large_mem_freq_and_tiny_clips(nets, monkeypatch, T, mem_freq, idx):
+    """Group formation corner cases: mem_freq above the 8-frame group cap, mem_freq beyond the clip (no insertion at
+    all), 3- and 2-frame clips; grouped decode must equal the frame-by-frame path."""
+    H, W = 112, 128
+    img = synth.synthetic_clip(T, H, W, seed=6)
+    msk = synth.synthetic_mask(T, H, W, 1, seed=7)
+    res = {}
+    for g in ("1", "8"):
+        monkeypatch.setenv("STCN_DECODE_BATCH", g)
+        core = make_core(nets)(img, 1, mem_freq)
+        m = core.interact(msk[:, idx], idx).copy()
+        res[g] = (m, core.prob.clone(), core.stats())
+    assert res["1"][2] == res["8"][2], "same frames, misses, insertions"
+    assert res["1"][2]["frames"] == T - 1
+    assert iou(res["8"][0], res["1"][0]) >= 1 - 1e-3
+    assert (res["8"][1] - res["1"][1]).abs().max().item() < 2e-3
+
+
 def test_reset_equals_fresh_engine(nets):
     T, H, W = 6, 112, 144
     img, msk = synth.synthetic_clip(T, H, W), synth.synthetic_mask(T, H, W, 1)
