@@ -311,8 +311,19 @@ def main():
                                "kernel": "conv_gemm_kernel (fp32 implicit-GEMM conv, v_mfma_f32_32x32x2_f32)",
                                "launches": conv["launches"], "avg_launch_ms": conv["ms"] / max(conv["launches"], 1),
                                "flop_per_launch_avg": conv["flops"] / max(conv["launches"], 1)}
+            hb = prof.pop("conv_hbm_bound")                      # subset of "conv": launches below 19.7 FLOP/B
             tot_ms = sum(v["ms"] for v in prof.values())
             out["kernel_time_share"] = {c: round(v["ms"] / tot_ms, 4) for c, v in prof.items() if v["ms"] > 0}
+            if hb["ms"] > 0 and conv["ms"] > hb["ms"]:
+                # the same kernel in its two regimes (the headline `roofline` above is over ALL its launches)
+                mf = (conv["flops"] - hb["flops"]) / ((conv["ms"] - hb["ms"]) * 1e-3) / 1e12
+                gb = hb["bytes"] / (hb["ms"] * 1e-3) / 1e9
+                out["roofline_by_regime"] = {
+                    "mfma_bound_launches": {"launches": conv["launches"] - hb["launches"], "time_share_of_conv": round(1 - hb["ms"] / conv["ms"], 4),
+                                            "achieved": mf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": mf / FP32_MFMA_PEAK_TFLOPS},
+                    "hbm_bound_launches": {"launches": hb["launches"], "time_share_of_conv": round(hb["ms"] / conv["ms"], 4),
+                                           "achieved": gb, "peak": 8000.0, "unit": "GB/s", "frac": gb / 8000.0,
+                                           "what": "conv launches under 19.7 FLOP/B of algorithmic intensity (1x1 channel expansions, stems)"}}
             # HBM-side bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate runs)
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))

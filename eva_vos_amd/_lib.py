@@ -53,6 +53,7 @@ PROTOTYPES = {
     "stcn_get_kernel_ms": (_I, [_P, C.POINTER(_F), C.POINTER(C.c_int32)]),
     "stcn_get_kernel_flops": (_I, [_P, C.POINTER(_D)]),
     "stcn_get_kernel_bytes": (_I, [_P, C.POINTER(_D)]),
+    "stcn_get_conv_regimes": (_I, [_P, C.POINTER(_D)]),
 }
 
 _lib = None

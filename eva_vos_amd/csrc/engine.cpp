@@ -24,13 +24,14 @@ const char *get_error() { return g_err; }
 // ---------------------------------------------------------------------------------------------- Prof
 void Prof::reset() {
     for (int i = 0; i < STCN_K_COUNT; ++i) { flops[i] = 0; bytes[i] = 0; launches[i] = 0; }
+    hbm_conv_flops = hbm_conv_bytes = hbm_conv_ms = 0; hbm_conv_launches = 0;
     for (auto &e : events) { pool.push_back(e.a); pool.push_back(e.b); }
     events.clear();
 }
 void Prof::begin(int cls, hipStream_t s) {
     launches[cls]++;
     if (!on) return;
-    Ev e; e.cls = cls;
+    Ev e; e.cls = cls; e.hbm = false;
     for (hipEvent_t *p : {&e.a, &e.b}) {
         if (!pool.empty()) { *p = pool.back(); pool.pop_back(); }
         else (void)hipEventCreate(p);
@@ -38,10 +39,11 @@ void Prof::begin(int cls, hipStream_t s) {
     (void)hipEventRecord(e.a, s);
     events.push_back(e);
 }
-hipEvent_t *Prof::attach(int cls) {
+hipEvent_t *Prof::attach(int cls, bool hbm) {
     launches[cls]++;
+    if (hbm) hbm_conv_launches++;
     if (!on) return nullptr;
-    Ev e; e.cls = cls;
+    Ev e; e.cls = cls; e.hbm = hbm;
     for (hipEvent_t *p : {&e.a, &e.b}) {
         if (!pool.empty()) { *p = pool.back(); pool.pop_back(); }
         else (void)hipEventCreate(p);
@@ -55,11 +57,13 @@ void Prof::end(hipStream_t s) {
 }
 int Prof::collect(float *ms) {
     for (int i = 0; i < STCN_K_COUNT; ++i) ms[i] = 0.f;
+    hbm_conv_ms = 0;
     for (auto &e : events) {
         if (hipEventSynchronize(e.b) != hipSuccess) return STCN_E_HIP;
         float t = 0.f;
         if (hipEventElapsedTime(&t, e.a, e.b) != hipSuccess) return STCN_E_HIP;
         ms[e.cls] += t;
+        if (e.hbm) hbm_conv_ms += t;
     }
     return STCN_OK;
 }
@@ -327,13 +331,19 @@ int run_conv(const Model &m, Work &w, hipStream_t s, const char *name, const flo
     p.partial = w.splitk;
     conv_plan(p, force_splitk, w.splitk_floats);
     const double fl = 2.0 * p.M * p.N * (double)(cw.kh * cw.kw * cw.cin);
-    if (w.prof)   // algorithmic bytes: input(s), weights, output and residual once each
-        w.prof->bytes[STCN_K_CONV] += 4.0 * ((double)p.x0_bytes / 4 + (double)p.x1_bytes / 4 + (double)cw.cout * cw.K +
-                                             (double)p.M * p.N * (res ? 2 : 1));
     hipEvent_t *eg = nullptr, *er = nullptr;
     if (w.prof) {
+        // algorithmic bytes: the input tensors (dense data, not the descriptor extents; a broadcast source once), weights,
+        // output and residual (a broadcast residual once), each once
+        const double in0 = (double)(bs0 ? B : 1) * H * W * c0, in1 = x1 ? (double)(bs1 ? B : 1) * H * W * c1 : 0.0;
+        const double resb = res ? (res_bs ? (double)p.M * p.N : (double)p.OH * p.OW * p.N) : 0.0;
+        const double bytes = 4.0 * (in0 + in1 + (double)cw.cout * cw.K + (double)p.M * p.N + resb);
+        // launches below the machine balance (157.3 TFLOP/s / 8 TB/s = 19.7 FLOP/B) are HBM-bound: accounted apart too
+        const bool hbm_bound = fl / bytes < 157.3e12 / 8.0e12;
+        w.prof->bytes[STCN_K_CONV] += bytes;
         w.prof->flops[STCN_K_CONV] += fl;
-        eg = w.prof->attach(STCN_K_CONV);
+        if (hbm_bound) { w.prof->hbm_conv_bytes += bytes; w.prof->hbm_conv_flops += fl; }
+        eg = w.prof->attach(STCN_K_CONV, hbm_bound);
         if (p.splitk > 1 || p.rem_split > 1) er = w.prof->attach(STCN_K_CONV_REDUCE);
     }
     conv_launch(p, s, eg, er);
@@ -1063,6 +1073,13 @@ int stcn_get_kernel_flops(const stcn_engine *e, double *flops) {
 int stcn_get_kernel_bytes(const stcn_engine *e, double *bytes) {
     if (!e || !bytes) return STCN_E_INVALID;
     for (int i = 0; i < STCN_K_COUNT; ++i) bytes[i] = e->prof.bytes[i];
+    return STCN_OK;
+}
+int stcn_get_conv_regimes(stcn_engine *e, double *out) {
+    if (!e || !out) return STCN_E_INVALID;
+    float ms[STCN_K_COUNT];
+    if (e->prof.on) { int rc = e->prof.collect(ms); if (rc) return rc; }
+    out[0] = e->prof.hbm_conv_flops; out[1] = e->prof.hbm_conv_bytes; out[2] = e->prof.hbm_conv_ms; out[3] = e->prof.hbm_conv_launches;
     return STCN_OK;
 }
 

@@ -63,13 +63,15 @@ struct Prof {
     double flops[STCN_K_COUNT] = {0};
     double bytes[STCN_K_COUNT] = {0};     // algorithmic HBM bytes (each operand once)
     int launches[STCN_K_COUNT] = {0};
-    struct Ev { int cls; hipEvent_t a, b; };    // a, b contiguous: attach() hands out &a as hipEvent_t[2]
+    struct Ev { int cls; bool hbm; hipEvent_t a, b; };    // a, b contiguous: attach() hands out &a as hipEvent_t[2]
     std::deque<Ev> events;                      // deque: attach() returns pointers into it
     std::vector<hipEvent_t> pool;
     void reset();
     void begin(int cls, hipStream_t s);
     // register an event pair that the launch itself will fill (hipExtLaunchKernelGGL); null when off
-    hipEvent_t *attach(int cls);
+    hipEvent_t *attach(int cls, bool hbm_bound_conv = false);
+    // conv launches below the machine balance (HBM-bound), also counted in the STCN_K_CONV totals
+    double hbm_conv_flops = 0, hbm_conv_bytes = 0, hbm_conv_ms = 0; int hbm_conv_launches = 0;
     void end(hipStream_t s);
     int collect(float *ms);
     ~Prof();

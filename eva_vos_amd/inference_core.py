@@ -157,7 +157,12 @@ class InferenceCore:
         _lib.check(_lib.lib().stcn_get_kernel_ms(self._engine, ms, ln))
         _lib.check(_lib.lib().stcn_get_kernel_flops(self._engine, fl))
         _lib.check(_lib.lib().stcn_get_kernel_bytes(self._engine, by))
-        return {c: dict(ms=ms[i], launches=ln[i], flops=fl[i], bytes=by[i]) for i, c in enumerate(_lib.K_CLASSES)}
+        out = {c: dict(ms=ms[i], launches=ln[i], flops=fl[i], bytes=by[i]) for i, c in enumerate(_lib.K_CLASSES)}
+        reg = (C.c_double * 4)()
+        _lib.check(_lib.lib().stcn_get_conv_regimes(self._engine, reg))
+        # conv launches below the machine balance (HBM-bound); a subset of the "conv" totals
+        out["conv_hbm_bound"] = dict(ms=reg[2], launches=int(reg[3]), flops=reg[0], bytes=reg[1])
+        return out
 
     def __deepcopy__(self, memo):
         new = object.__new__(InferenceCore)

@@ -161,6 +161,10 @@ int stcn_get_kernel_ms(const stcn_engine *e, float *ms /*[STCN_K_COUNT]*/, int32
 int stcn_get_kernel_flops(const stcn_engine *e, double *flops /*[STCN_K_COUNT]*/);
 /* Algorithmic HBM bytes (every operand of every launch once; conv class only) of the last interact(). */
 int stcn_get_kernel_bytes(const stcn_engine *e, double *bytes /*[STCN_K_COUNT]*/);
+/* Conv launches of the last interact() whose arithmetic intensity (algorithmic FLOP / algorithmic bytes) lies below the
+ * machine balance 157.3 TFLOP/s / 8 TB/s = 19.7 FLOP/B - HBM-bound, e.g. the 1x1 channel expansions of the key encoder.
+ * They are part of the STCN_K_CONV totals; out[4] = { FLOP, bytes, device ms (profiling on), launches }. */
+int stcn_get_conv_regimes(stcn_engine *e, double *out /*[4]*/);
 
 /* Debug stress test: victim kernel (0 = memory-read merge stage, 1 = plain gather-sum) on one stream, conv kernels
  * (conv_mode 0 = fp32, 1 = f16x3, -1 = none) on another, `iters` overlapped repetitions; reports how many victim
