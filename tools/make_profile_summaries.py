@@ -38,7 +38,7 @@ conv_ns = sum(float(r["TotalDurationNs"]) for r in conv)
 roof = bench["roofline"]
 lines = [f"# rocprofv3 --kernel-trace --stats - {tag}, final engine of the round (solo launches)", "",
          "Command (GPU box): `cd /tmp && STCN_LOOKAHEAD=0 rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py "
-         "--streams 1 --steps 2 --warmup 1 --cpu-frames 0 --no-profile --no-f16x3-leg`",
+         "--streams 1 --steps 2 --warmup 1 --cpu-frames 0 --no-profile --no-f16x3-leg --no-r2`",
          f"{trace_bench['steps'] + trace_bench['warmup']} videos x {trace_bench['config']['frames_per_step']} propagated frames (480x854, k=1, "
          "mem_freq=5), one video in flight, no side stream: the same solo launches bench.py's roofline leg times with HIP events.", "",
          f"Total kernel time {tot / 1e6:.1f} ms = {tot / 1e6 / frames:.2f} ms per propagated frame.", "",
@@ -92,7 +92,7 @@ cg = [k for k in kernels if "conv_gemm_kernel" in k]
 n = sum(kernels[k]["calls"] for k in cg)
 traffic = sum(kernels[k]["traffic_bytes_per_launch"] * kernels[k]["calls"] for k in cg) / n
 out = dict(command="rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) --kernel-trace -- python3 bench.py --steps 1 --warmup 0 --streams 1 "
-                   "--cpu-frames 0 --no-profile --no-f16x3-leg --frames 30 (STCN_LOOKAHEAD=0)",
+                   "--cpu-frames 0 --no-profile --no-f16x3-leg --no-r2 --frames 30 (STCN_LOOKAHEAD=0)",
            units="counter values are KB per the rocprofv3 derived metric; gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reads 1/2 of the "
                  "bytes of wide (16 B/lane) coalesced reads -> doubled; WRITE_SIZE exact; Infinity-Cache hits are included (fabric-side counters)",
            conv_gemm_traffic_bytes_per_launch=traffic, conv_gemm_launches=n, kernels=kernels)
