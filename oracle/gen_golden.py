@@ -192,6 +192,7 @@ SEQ_CASES = {
 STAGE_CASES = {
     "stA": dict(H=128, W=160, k=1),
     "stB": dict(H=100, W=150, k=3),
+    "stC": dict(H=96, W=208, k=2),       # wide frame (6 x 13 keys), two objects
 }
 
 
@@ -202,7 +203,13 @@ def main():
     if only:
         for tag in only:
             out = {}
-            rep = seq_case(tag, net=net, fus=fus, psd=psd, fsd=fsd, out=out, **SEQ_CASES[tag])
+            if tag in STAGE_CASES:
+                c = STAGE_CASES[tag]
+                rep = stage_case(tag, c["H"], c["W"], c["k"], net, psd, out)
+                rep.update(fusion_case(tag, c["H"], c["W"], fus, fsd, out))
+                rep = {k: f"{v:.2e}" for k, v in rep.items()}
+            else:
+                rep = seq_case(tag, net=net, fus=fus, psd=psd, fsd=fsd, out=out, **SEQ_CASES[tag])
             np.savez_compressed(os.path.join(GOLD, f"{tag}.npz"), **out)
             print(tag, rep)
         return

@@ -10,7 +10,7 @@ from gpu_util import call, dev, model_handle, rows_to_nchw, stream
 from oracle import stcn_oracle as O
 
 pytestmark = pytest.mark.gpu
-STAGE = {"stA": (128, 160, 1), "stB": (100, 150, 3)}
+STAGE = {"stA": (128, 160, 1), "stB": (100, 150, 3), "stC": (96, 208, 2)}
 
 
 def gpu_encode_key(nets, img):

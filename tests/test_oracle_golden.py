@@ -8,7 +8,7 @@ from conftest import iou, load_golden, rel_err, sample_of
 from eva_vos_amd import synth
 from oracle import stcn_oracle as O
 
-STAGE = {"stA": (128, 160, 1), "stB": (100, 150, 3)}
+STAGE = {"stA": (128, 160, 1), "stB": (100, 150, 3), "stC": (96, 208, 2)}
 
 
 def _rows(x):
