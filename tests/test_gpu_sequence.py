@@ -239,6 +239,22 @@ def test_decode_groups_with_large_mem_freq_and_tiny_clips(nets, monkeypatch, T, 
     assert (res["8"][1] - res["1"][1]).abs().max().item() < 2e-3
 
 
+def test_inputs_on_the_host_or_in_other_layouts_give_the_same_result(nets):
+    """The reference accepts images / masks on any device (it moves them, inference_core.py:44-68,216-220); the shim
+    moves and converts: CPU tensors, float64, non-contiguous views and an explicit device string."""
+    from mivos.inference_core import InferenceCore
+    T, H, W = 5, 112, 144
+    img, msk = synth.synthetic_clip(T, H, W, seed=8), synth.synthetic_mask(T, H, W, 1, seed=9)
+    ref = InferenceCore(nets[0], nets[1], img.cuda(), 1).interact(msk[:, 2].cuda(), 2)
+    wide = torch.zeros(1, T, 3, H, W + 6, dtype=torch.float64)
+    wide[..., 3:W + 3] = img
+    a = InferenceCore(nets[0], nets[1], wide[..., 3:W + 3], 1, device="cuda:0").interact(msk[:, 2].double(), 2)   # CPU, f64, strided
+    assert np.array_equal(a, ref)
+    core = InferenceCore(nets[0], nets[1], img, 1, mem_profile=2)                                               # CPU clip, spill mode
+    assert np.array_equal(core.interact(msk[:, 2], np.int64(2)), ref) and core.prob.is_cuda
+    assert core.interact(msk[:, 2], 2, download=False) is None
+
+
 def test_reset_equals_fresh_engine(nets):
     T, H, W = 6, 112, 144
     img, msk = synth.synthetic_clip(T, H, W), synth.synthetic_mask(T, H, W, 1)
