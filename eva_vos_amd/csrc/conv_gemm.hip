@@ -42,6 +42,23 @@ static constexpr int LDT = 36;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 static constexpr unsigned OOB = 0x80000000u;    // byte offset beyond any tensor: buffer loads return 0
 
+// tile index -> (m-tile, n-tile).  Default: n fastest (the n-tiles of one m-tile run side by side and share its im2col
+// rows in L2).  With more than `pn` n-tiles the tiles are walked in panels of `pn` n-tiles (STCN_CONV_PANEL, default 4):
+// the weight slices in flight shrink to one panel, at the price of fetching the activations once per panel - measured
+// on up_16_8.skip_conv over a 5-frame group with 64x64 tiles: FETCH_SIZE 652 -> 348 MB (panels of 4), 250 MB (of 2);
+// over the whole path -10 % (the heavy shapes run on 128x128 tiles, which already fetch 3.8x less), same speed.
+__device__ __forceinline__ void tile_to_mn(int tile, int tiles_n, int ntile, int pn, int &tm, int &tn) {
+    if (pn > 0 && tiles_n % pn == 0 && tiles_n > pn) {
+        const int tiles_m = ntile / tiles_n, per_panel = tiles_m * pn;
+        const int panel = tile / per_panel, rem = tile - panel * per_panel;
+        tm = rem / pn;
+        tn = panel * pn + (rem - tm * pn);
+    } else {
+        tm = tile / tiles_n;
+        tn = tile - tm * tiles_n;
+    }
+}
+
 // WM x WN waves per workgroup, each owning RM x RN accumulator blocks of 32x32: workgroup tile (32 WM RM) x (32 WN RN).
 template <int WM, int WN, int RM, int RN, bool SMALLC, bool RELU>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvP p, const int tiles_n,
@@ -77,7 +94,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvP p, const int
         split = swz / ntile;
         tile = swz - split * ntile;
     }
-    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    int tm, tn;
+    tile_to_mn(tile, tiles_n, ntile, p.panel, tm, tn);
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / WN, wn = wave - wm * WN;
@@ -370,12 +388,13 @@ __global__ __launch_bounds__(256) void conv_reduce_kernel(const ConvP p) {
 }
 
 // tail balancing: y(tile) = sum over the K pieces of the tile-local partials + epilogue; one block per 32 tile rows
-__global__ __launch_bounds__(256) void conv_reduce_tiles_kernel(const ConvP p, const int tiles_n, const int BM, const int BN) {
+__global__ __launch_bounds__(256) void conv_reduce_tiles_kernel(const ConvP p, const int tiles_n, const int ntile, const int BM, const int BN) {
     const int rows_per_blk = 1024 / BN;                          // 256 threads x 4 columns
     const int blks_per_tile = BM / rows_per_blk;
     const int rt = blockIdx.x / blks_per_tile, rb = blockIdx.x - rt * blks_per_tile;
     const int tile = p.rem_full + rt;
-    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    int tm, tn;
+    tile_to_mn(tile, tiles_n, ntile, p.panel, tm, tn);
     const int e4 = threadIdx.x * 4;
     const int row = rb * rows_per_blk + e4 / BN, col = e4 - (e4 / BN) * BN;
     const int m = tm * BM + row, n = tn * BN + col;
@@ -457,6 +476,8 @@ void conv_plan(ConvP &p, int force_splitk, size_t ws_floats) {
         const Plan pb = plan_variant(p, true, force_splitk, ws_floats);
         if (pb.cost < pl.cost || big_mode >= 2) pl = pb;
     }
+    static const int panel_env = [] { const char *e = getenv("STCN_CONV_PANEL"); return e ? atoi(e) : 4; }();
+    p.panel = (p.mode & 1) ? 0 : panel_env;
     p.tile_big = pl.big; p.splitk = pl.splitk;
     p.rem_full = pl.rem_full; p.rem_split = pl.rem_split; p.rem_per = pl.rem_per;
     static const bool dbg = getenv("STCN_CONV_PLAN_DEBUG") != nullptr;
@@ -515,9 +536,9 @@ void conv_launch(const ConvP &p, hipStream_t s, hipEvent_t *ev_gemm, hipEvent_t 
     if (tail) {
         const unsigned blocks = (unsigned)((ntile - p.rem_full) * (BM * BN / 1024));
         if (ev_red)
-            hipExtLaunchKernelGGL(conv_reduce_tiles_kernel, dim3(blocks), dim3(256), 0, s, ev_red[0], ev_red[1], 0, p, tiles_n, BM, BN);
+            hipExtLaunchKernelGGL(conv_reduce_tiles_kernel, dim3(blocks), dim3(256), 0, s, ev_red[0], ev_red[1], 0, p, tiles_n, ntile, BM, BN);
         else
-            hipLaunchKernelGGL(conv_reduce_tiles_kernel, dim3(blocks), dim3(256), 0, s, p, tiles_n, BM, BN);
+            hipLaunchKernelGGL(conv_reduce_tiles_kernel, dim3(blocks), dim3(256), 0, s, p, tiles_n, ntile, BM, BN);
     } else if (p.splitk > 1) {
         const long total4 = (long)p.M * p.N / 4;
         long blocks = (total4 + 255) / 256;

@@ -35,6 +35,7 @@ struct ConvP {
     // ([(tile - rem_full) * rem_split + piece][BM][BN]) and are summed by conv_reduce_tiles_kernel
     int rem_full, rem_split, rem_per;
     int tile_big;           // 1 = 128x128 workgroup tiles (fp32 kernel)
+    int panel;              // > 0: tiles are walked in panels of this many n-tiles (fp32 kernel)
 };
 // fills the launch plan of p (tile variant, split-K or tail balancing); force_splitk > 0 pins a plain split-K;
 // workspace_floats = capacity of p.partial
