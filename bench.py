@@ -36,7 +36,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks (one per GPU); default = WORLD_SIZE or 1")
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=66, help="frames per video (DAVIS-17 val mean length ~66)")
@@ -102,11 +102,32 @@ def parity_vs_oracle(prop, fuse, sample, mem_freq):
                 j_and_f_hip=float(jf_gpu), j_and_f_cpu_oracle=float(jf_cpu))
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` outside torch.distributed.run: this process - which has not touched the GPU (no
+    torch.cuda call, libstcn_hip.so not loaded) - starts N fresh rank processes through torch.distributed.run (one per
+    GPU, rendezvous on 127.0.0.1), lets them print (rank 0 prints the JSON line) and returns their exit status.  The
+    reference shards the same way by hand: one process per `--min-idx/--max-idx` slice
+    (eval_annotation_method.py:34-35,118-119; datasets/annotation_dataset.py:56-59)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
 def main():
     a = parse()
+    if a.gpus is not None and a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a.gpus))
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    if a.gpus is None:
+        a.gpus = world
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node equal to --gpus"
     torch.set_grad_enabled(False)
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (there is no CPU fallback of the product)"
     # STCN_BENCH_DEVICE / STCN_BENCH_BACKEND exist only to exercise the multi-rank path on a 1-GPU box

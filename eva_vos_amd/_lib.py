@@ -43,6 +43,7 @@ PROTOTYPES = {
     "stcn_test_encode_key": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "stcn_test_encode_value": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "stcn_test_memory_read": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
+    "stcn_bench_memory_read": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, C.POINTER(_F), C.POINTER(C.c_int32)]),
     "stcn_test_decode": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
     "stcn_test_attention": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "stcn_test_fusion": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _I, _I, _P]),

@@ -28,6 +28,7 @@
 #include <mutex>
 #include <set>
 #include <type_traits>
+#include <utility>
 
 #include "kernels.h"
 
@@ -486,13 +487,16 @@ void conv_plan(ConvP &p, int force_splitk, size_t ws_floats) {
                 pl.big ? "128x128" : (narrow_variant(p) ? "128x32" : "64x64"), pl.splitk, pl.rem_full, pl.rem_split, pl.rem_per, pl.cost);
 }
 
-// dynamic LDS above 64 KB has to be opted into once per kernel function (one process drives one GPU)
-static void allow_big_lds(const void *kernel, size_t lds) {
+// dynamic LDS above 64 KB has to be opted into once per (device, kernel function): a process may hold models on several
+// devices and drive them from several host threads (lanes)
+void allow_big_lds(const void *kernel, size_t lds) {
     if (lds <= 64 * 1024) return;
     static std::mutex mu;
-    static std::set<const void *> done;
+    static std::set<std::pair<int, const void *>> done;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> g(mu);
-    if (done.insert(kernel).second)
+    if (done.insert({dev, kernel}).second)
         (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 

@@ -285,11 +285,13 @@ int Work::init(int nh, int nw, int k_, int key_batch, int group) {
     if ((rc = alloc((void **)&amap, (size_t)(k + 1) * 2 * d.hw16 * sizeof(float)))) return rc;
     if ((rc = alloc((void **)&attn, (size_t)(k + 1) * 2 * d.npix * sizeof(float)))) return rc;
     // memory-read scratch for Q = group * hw16 queries (a decode group is read in one pass)
-    if ((rc = alloc((void **)&cand_v, (size_t)16 * group * d.hw16 * 50 * sizeof(float)))) return rc;
-    if ((rc = alloc((void **)&cand_i, (size_t)16 * group * d.hw16 * 50 * sizeof(int32_t)))) return rc;
+    const size_t pairs = memread_list_pairs(group * d.hw16);   // (chunk, query) lists of the largest read (a decode group)
+    if ((rc = alloc((void **)&cand_v, pairs * 50 * sizeof(float)))) return rc;
+    if ((rc = alloc((void **)&cand_i, pairs * 50 * sizeof(int32_t)))) return rc;
+    if ((rc = alloc((void **)&cand_n, pairs * sizeof(int32_t)))) return rc;
     if ((rc = alloc((void **)&qk, (size_t)group * d.hw16 * 64 * sizeof(float)))) return rc;
     if ((rc = alloc((void **)&vin, (size_t)k * d.npix * 8 * sizeof(float)))) return rc;
-    if ((rc = alloc((void **)&gmax, (size_t)256 * group * d.hw16 * sizeof(float)))) return rc;
+    if ((rc = alloc((void **)&gmax, pairs * 64 * sizeof(float)))) return rc;
     if ((rc = alloc((void **)&tau, (size_t)group * d.hw16 * sizeof(float)))) return rc;
     return STCN_OK;
 }
@@ -850,6 +852,9 @@ static int ensure_key(stcn_engine *e, int ti, SlotPtrs *out) {
 }
 
 static void dbg_sum(stcn_engine *e, const char *tag, int ti, const float *p, size_t n);
+// algorithmic bytes of one memory read: the key bank (+ |mk|^2) and the queries once, 50 gathered value
+// rows of 2 KB per query and object, the readout once; the N x Q affinity is not traffic (it must stay on-chip)
+static double memread_bytes(double N, double Q, double k) { return 4.0 * (N * 65 + Q * 64 + k * Q * 50 * 512 + k * Q * 512); }
 static float *bank_v_slot(stcn_engine *e, int slot) { return e->bank_v + (size_t)slot * e->d.hw16 * 512; }
 
 // write key (from cache) + freshly encoded value of frame ti into bank slot `slot`
@@ -937,8 +942,9 @@ static int do_pass(stcn_engine *e, int idx, bool forward) {
         const int N = m_front * d.hw16;
         auto read = [&](const SlotPtrs &f, float *readout) {
             Scope sc(&e->prof, STCN_K_MEMREAD, e->stream, 2.0 * N * d.hw16 * 64 + 2.0 * k * d.hw16 * 50 * 512);
+            e->prof.bytes[STCN_K_MEMREAD] += memread_bytes(N, d.hw16, k);
             memory_read_launch(e->bank_k, e->bank_msq, f.k16, N, d.hw16, e->bank_v, (long)e->bank_cap * d.hw16 * 512, k, readout,
-                               (long)d.hw16 * 512, nullptr, nullptr, MemReadScratch{w.cand_v, w.cand_i, w.gmax, w.tau}, e->stream);
+                               (long)d.hw16 * 512, nullptr, nullptr, MemReadScratch{w.cand_v, w.cand_i, w.cand_n, w.gmax, w.tau}, e->stream);
         };
         // agg of the frame at sweep position g lives at w.agg + pos(g) * agg_fs
         auto pos = [&](int g) { return batched ? (ti + g * step) - t_lo : 0; };
@@ -950,8 +956,9 @@ static int do_pass(stcn_engine *e, int idx, bool forward) {
             }
             {
                 Scope sc(&e->prof, STCN_K_MEMREAD, e->stream, G * (2.0 * N * d.hw16 * 64 + 2.0 * d.hw16 * 50 * 512));
+                e->prof.bytes[STCN_K_MEMREAD] += memread_bytes(N, G * d.hw16, 1);
                 memory_read_launch(e->bank_k, e->bank_msq, w.qk, N, G * d.hw16, e->bank_v, (long)e->bank_cap * d.hw16 * 512, 1,
-                                   w.readout, (long)G * d.hw16 * 512, nullptr, nullptr, MemReadScratch{w.cand_v, w.cand_i, w.gmax, w.tau},
+                                   w.readout, (long)G * d.hw16 * 512, nullptr, nullptr, MemReadScratch{w.cand_v, w.cand_i, w.cand_n, w.gmax, w.tau},
                                    e->stream);
             }
             RC(decode(*e->model, w, e->stream, w.readout, f0.f16_thin, f0.s8, f0.s4, w.agg, d.npix, f0.dthin, f0.cthin, G,

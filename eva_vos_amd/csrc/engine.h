@@ -90,7 +90,7 @@ struct Work {
     float *flogit = nullptr;            // [k][npix]  fusion logits
     float *agg = nullptr;               // [k+1][npix] aggregated output of the current frame
     float *pooled = nullptr, *amap = nullptr, *attn = nullptr;   // attention read
-    float *cand_v = nullptr; int32_t *cand_i = nullptr;          // memory-read chunk winners
+    float *cand_v = nullptr; int32_t *cand_i = nullptr, *cand_n = nullptr;   // memory-read chunk winners
     float *gmax = nullptr, *tau = nullptr;                       // memory-read group maxima / thresholds
     float *qk = nullptr;                // [group][hw16][64] queries of a decode group
     float *vin = nullptr;               // value-encoder packed input [k][npix][8]

@@ -159,14 +159,49 @@ int stcn_test_memory_read(void *stream, const float *mk, const float *mv, const 
                           int32_t *topk_idx, float *topk_w, float *readout) {
     if (!mk || !mv || !qk || !readout || N < 50 || Q < 1 || k < 1) { set_error("stcn_test_memory_read: bad arguments (N >= 50)"); return STCN_E_INVALID; }
     hipStream_t s = (hipStream_t)stream;
-    DevBuf msq, cv, ci, gm, tau;
-    RC(msq.alloc(N + 64)); RC(cv.alloc((size_t)16 * Q * 50)); RC(ci.alloc((size_t)16 * Q * 50));
-    RC(gm.alloc((size_t)256 * Q)); RC(tau.alloc(Q));
+    DevBuf msq, cv, ci, cn, gm, tau;
+    const size_t pairs = memread_list_pairs(Q);
+    RC(msq.alloc(N + 64)); RC(cv.alloc(pairs * 50)); RC(ci.alloc(pairs * 50)); RC(cn.alloc(pairs));
+    RC(gm.alloc(pairs * 64)); RC(tau.alloc(Q));
     HIPCHK(hipMemsetAsync(msq.p, 0, (size_t)(N + 64) * 4, s));
     rowsumsq_launch(mk, N, 64, msq.p, s);
     memory_read_launch(mk, msq.p, qk, N, Q, mv, (long)N * 512, k, readout, (long)Q * 512, topk_idx, topk_w,
-                       MemReadScratch{cv.p, reinterpret_cast<int32_t *>(ci.p), gm.p, tau.p}, s);
+                       MemReadScratch{cv.p, reinterpret_cast<int32_t *>(ci.p), reinterpret_cast<int32_t *>(cn.p), gm.p, tau.p}, s);
     HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    return STCN_OK;
+}
+
+// Timed memory reads on caller-provided device data: `iters` whole reads (pass 1, threshold, pass 2, merge + gather) between
+// two HIP events on `stream`; scratch is allocated once, outside the timed region.  ms = average per read.
+int stcn_bench_memory_read(void *stream, const float *mk, const float *mv, const float *qk, int N, int Q, int k, int iters,
+                           float *readout, float *ms, int32_t *plan7) {
+    if (!mk || !mv || !qk || !readout || !ms || N < 50 || Q < 1 || k < 1 || iters < 1) { set_error("stcn_bench_memory_read: bad arguments"); return STCN_E_INVALID; }
+    hipStream_t s = (hipStream_t)stream;
+    DevBuf msq, cv, ci, cn, gm, tau;
+    const size_t pairs = memread_list_pairs(Q);
+    RC(msq.alloc(N + 64)); RC(cv.alloc(pairs * 50)); RC(ci.alloc(pairs * 50)); RC(cn.alloc(pairs));
+    RC(gm.alloc(pairs * 64)); RC(tau.alloc(Q));
+    HIPCHK(hipMemsetAsync(msq.p, 0, (size_t)(N + 64) * 4, s));
+    rowsumsq_launch(mk, N, 64, msq.p, s);
+    const MemReadScratch scr{cv.p, reinterpret_cast<int32_t *>(ci.p), reinterpret_cast<int32_t *>(cn.p), gm.p, tau.p};
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    for (int it = 0; it < 2; ++it)
+        memory_read_launch(mk, msq.p, qk, N, Q, mv, (long)N * 512, k, readout, (long)Q * 512, nullptr, nullptr, scr, s);
+    HIPCHK(hipEventRecord(e0, s));
+    for (int it = 0; it < iters; ++it)
+        memory_read_launch(mk, msq.p, qk, N, Q, mv, (long)N * 512, k, readout, (long)Q * 512, nullptr, nullptr, scr, s);
+    HIPCHK(hipEventRecord(e1, s));
+    HIPCHK(hipEventSynchronize(e1));
+    HIPCHK(hipEventElapsedTime(ms, e0, e1));
+    *ms /= (float)iters;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (plan7) {
+        const MemReadPlan pl = memread_plan(N, Q);
+        const int v[7] = {pl.steps, pl.ss, pl.ns, pl.nc1, pl.spc1, pl.nc2, pl.spc2};
+        for (int i = 0; i < 7; ++i) plan7[i] = v[i];
+    }
     HIPCHK(hipGetLastError());
     return STCN_OK;
 }

@@ -89,8 +89,16 @@ void cbam_launch(const float *x, float *out, int B, int h, int w, const CbamW &c
                  hipStream_t s);
 
 // ---------------------------------------------------------------- space-time memory read
-struct MemReadScratch { float *cand_v; int32_t *cand_i; float *gmax; float *tau; };   // [16][Q][50] x2, [256][Q], [Q]
-int  memread_num_chunks(int N);
+// launch plan of the top-50 read: `steps` 64-row steps of the bank; pass 1 visits every ss-th step (ns of them) in nc1 chunks of
+// spc1 sampled steps, pass 2 all steps in nc2 chunks of spc2
+struct MemReadPlan { int steps, ss, ns, nc1, spc1, nc2, spc2; };
+MemReadPlan memread_plan(int N, int Q);
+// upper bound of (chunks x queries) of either pass for Q queries: sizes the scratch below
+size_t memread_list_pairs(int Q);
+// P = memread_list_pairs(Q): cand_v / cand_i [P][50], cand_n [P], gmax [64 P], tau [Q]
+struct MemReadScratch { float *cand_v; int32_t *cand_i; int32_t *cand_n; float *gmax; float *tau; };
+// dynamic LDS above 64 KB has to be opted into once per (device, kernel function)
+void allow_big_lds(const void *kernel, size_t lds);
 // mk [N,64], msq [N] (+ >= 64 readable floats of padding), qk [Q,64]; mv [k][N][512] with object stride mv_os; readout [k][Q][512] with
 // row stride ro_ld (floats) and object stride ro_os.  topk_idx/topk_w optional outputs [Q,50].
 void memory_read_launch(const float *mk, const float *msq, const float *qk, int N, int Q,

@@ -17,6 +17,9 @@
 //   merge_readout: one wave per query merges the chunk lists, softmaxes the 50 with wavefront
 //     reductions and gathers 50 value rows (2 KB each, NHWC bank) per object.
 //   The column-constant -|qk|^2 term cancels in exp(v - v_max) and is dropped.
+#include <cstdlib>
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace stcn {
@@ -28,8 +31,10 @@ static constexpr int CAP = 128;       // per-(query, chunk) candidate list capac
 static constexpr int TROWS = 128;     // memory rows per tile of the attention read
 static constexpr int HROWS = 64;      // rows per step of the top-k passes
 static constexpr int SLD = 132;       // attention-read S slab row stride (floats)
-static constexpr int MAXCHUNK = 16;   // row chunks (grid.y) of the top-k passes
-static constexpr int NGRP = 16;       // running maxima per lane-group: 4 lane groups x 4 row blocks
+static constexpr int MAXCHUNK = 16;   // row chunks (grid.y) of the attention read
+static constexpr int NGRP = 16;       // attention read: running maxima per lane-group: 4 lane groups x 4 row blocks
+static constexpr int MAXCHUNK1 = 8;   // row chunks of pass 1 of the top-k read (64 maxima each: threshold_kernel takes <= 512)
+static constexpr int MAXCHUNK2 = 32;  // row chunks of pass 2 (merge_readout stages MAXCHUNK2 * 50 entries per query)
 
 __device__ __forceinline__ unsigned f2key(float f) {          // order-preserving float -> uint
     const unsigned u = __float_as_uint(f);
@@ -48,8 +53,8 @@ __device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)
 // Returns the TOPK-th best value; the list is compacted to exactly TOPK entries.
 __device__ __forceinline__ float wave_select128(float *lv, int *li, int n, int lane) {
     lds_fence();
-    const float f0 = lv[lane], f1 = lv[lane + 64];
-    const int i0 = li[lane], i1 = li[lane + 64];
+    const float f0 = lane < n ? lv[lane] : 0.f, f1 = lane + 64 < n ? lv[lane + 64] : 0.f;
+    const int i0 = lane < n ? li[lane] : 0, i1 = lane + 64 < n ? li[lane + 64] : 0;
     const unsigned k0 = lane < n ? f2key(f0) : 0u, k1 = lane + 64 < n ? f2key(f1) : 0u;   // key 0 < every real key
     unsigned prefix = 0;
     for (int bit = 31; bit >= 0; --bit) {
@@ -113,129 +118,274 @@ __device__ __forceinline__ void load_bq(const float *__restrict__ qk, int Q, int
     for (int kb = 0; kb < 4; ++kb) bq[kb] = *reinterpret_cast<const f32x4 *>(bp + 16 * kb);
 }
 
-// COLLECT == false: pass 1, writes gmax[(chunk*NGRP + 4*(lane>>4) + rb)][q] (running maxima).
-// COLLECT == true : pass 2, filters against tau[q] and writes the chunk's winners cand[chunk][q][TOPK].
-template <int WAVES, bool COLLECT>
-__global__ __launch_bounds__(64 * WAVES) void affinity_pass_kernel(
-    const float *__restrict__ mk, const float *__restrict__ msq, const float *__restrict__ qk, int N, int Q,
-    int steps_per_chunk, float *__restrict__ gmax, const float *__restrict__ tau_in, float *__restrict__ cand_v,
-    int32_t *__restrict__ cand_i) {
+// ------------------------------------------------------------------------------------------------
+// Tile kernel of the top-50 read (both passes).  One workgroup = 4 waves = 64 queries (16 per wave, resident in
+// registers as MFMA B fragments) x one chunk of 64-row steps of the bank.  The 64x64 key tile of a step (+ its 64 |mk|^2)
+// is staged ONCE per workgroup: global -> registers (issued a whole step ahead) -> LDS (double-buffered, 16-byte chunks
+// XOR-swizzled by the row so both the ds_write_b128 of the staging and the ds_read_b128 of the A fragments are
+// conflict-free) and shared by the 4 waves - the first version of this read fetched the tile once per wave
+// straight from L2 and ran at ~0.4 of the fp32 MFMA rate on L2 bandwidth.
+//   COLLECT == false (pass 1): visits only every `ss`-th step (a strided SAMPLE of the bank) and keeps 16 running maxima
+//     per lane over disjoint row sets: gmax[(chunk*64 + 16*(lane>>4) + 4*rb + j)][q].  The 50th largest of >= 50 maxima of
+//     disjoint subsets of the rows is a lower bound of the query's true 50th best score whatever the subsets are, so
+//     sampling costs tightness (expected rank ~ 52*ss instead of ~ 52), never exactness - and 1/ss of the MFMA work.
+//   COLLECT == true (pass 2): the full walk; scores above the query's threshold are appended to per-(query, chunk) lists
+//     in LDS (LDS atomics); a list that could overflow within the next 32 rows is cut back to its best 50 by the wave
+//     radix select, which also raises that query's threshold (only adversarial orderings get there).
+static constexpr int CAP2 = 64;                                         // list capacity (any value in (TOPK, 128] works, see below)
+static constexpr int KT_FLOATS = HROWS * 64 + HROWS;                    // key tile + (-|mk|^2 / 2) of one step
+static constexpr int LISTS_PER_WAVE = 2 * 16 * CAP2 + 32;               // LV, LI, CNT, TAU
+static constexpr int NGRP2 = 64;                                        // pass-1 maxima per query per chunk
+
+template <bool COLLECT>
+__global__ __launch_bounds__(256, 2) void affinity_tile_kernel(
+    const float *__restrict__ mk, const float *__restrict__ msq, const float *__restrict__ qk, int N, int Q, int ns,
+    int ss, int spc, float *__restrict__ gmax, const float *__restrict__ tau_in, float *__restrict__ cand_v,
+    int32_t *__restrict__ cand_i, int32_t *__restrict__ cand_n) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int PER_WAVE = 2 * 16 * CAP + 32;                         // floats of LDS per wave (pass 2)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float *LV = smem + wave * PER_WAVE;                                 // [16][CAP]
-    int *LI = reinterpret_cast<int *>(LV + 16 * CAP);                   // [16][CAP]
-    int *CNT = LI + 16 * CAP;                                           // [16]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    float *KT = smem;                                                   // [2][KT_FLOATS]
+    float *LV = smem + 2 * KT_FLOATS + wave * LISTS_PER_WAVE;           // [16][CAP2]      (pass 2 only)
+    int *LI = reinterpret_cast<int *>(LV + 16 * CAP2);                  // [16][CAP2]
+    int *CNT = LI + 16 * CAP2;                                          // [16]
     float *TAU = reinterpret_cast<float *>(CNT + 16);                   // [16]
 
+    const int q0 = (blockIdx.x * 4 + wave) * 16;                        // may be >= Q: the wave still stages tiles
+    const int chunk = blockIdx.y;
+    const int j0 = chunk * spc, j1 = min(ns, j0 + spc);                 // (sampled) steps of this chunk
+    const int g = lane >> 4, col = lane & 15;
+    const int qcol = min(q0 + col, Q - 1);
+
+    f32x4 bq[4];
+    load_bq(qk, Q, min(q0, Q - 1), lane, bq);
+    // the kernel works on U = mk.qk - |mk|^2/2 = 4 S (S = the reference's affinity up to the per-query constant): maxima
+    // and thresholds are compared unscaled, a score is multiplied by 1/4 (exact) when it leaves the kernel
+    float tcol = -__builtin_inff();
+    f32x4 gm[4];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) gm[rb] = f32x4{tcol, tcol, tcol, tcol};
+    if (COLLECT) {
+        tcol = 4.f * tau_in[qcol];
+        if (lane < 16) { CNT[lane] = 0; TAU[lane] = tcol; }
+        lds_fence();
+    }
+
+    // Staging: thread t moves the 16-byte chunks t, t+256, t+512, t+768 of the 64x16-chunk tile.  Buffer loads: rows beyond
+    // the bank read as zero in hardware (no clamping), the step's row offset is one scalar.  Every per-thread offset below
+    // is loop-invariant: the fp32 MFMA shares issue with VALU work, so the step loop carries ~5 address VALU ops in all
+    // (first version: 2.4 - 3.7 VALU per MFMA, 0.44 of the MFMA rate).
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(mk), 0, (unsigned)N * 256u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(msq), 0, (unsigned)N * 4u, 0x00020000);
+    const unsigned voff_k = (unsigned)((t >> 4) * 256 + (t & 15) * 16), voff_m = (unsigned)((t & 63) * 4);
+    const int st_off = (t >> 4) * 64 + (((t & 15) ^ ((t >> 4) & 15)) << 2);     // floats; chunk i adds 16 rows = 1024 floats
+    int a_off[4];                                                               // A fragment of k block kb; row block rb adds 1024
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) a_off[kb] = col * 64 + (((g | (kb << 2)) ^ col) << 2);
+    const int m_off = HROWS * 64 + 4 * g;                                       // accumulator init; row block rb adds 16
+    const int l_off = col * CAP2;
+    f32x4 st[4];
+    float stm = 0.f;
+    auto gload = [&](int h) {                                                   // step h (may lie beyond the bank: zeros)
+        const unsigned vk = voff_k + (unsigned)h * (HROWS * 256u), vm = voff_m + (unsigned)h * (HROWS * 4u);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) st[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rk, vk, i * 4096, 0));
+        stm = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm, vm, 0, 0));
+    };
+    auto sstore = [&](float *kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4 *>(kt + st_off + i * 1024) = st[i];
+        if (t < HROWS) kt[HROWS * 64 + t] = -0.5f * stm;                        // the accumulators start from -|mk|^2 / 2
+    };
+    if (j0 < j1) {
+        gload(j0 * ss);
+        sstore(KT);
+        gload((j0 + 1) * ss);
+    }
+    __syncthreads();
+
+    auto step = [&](const int j, auto bufc) {
+        constexpr int BUF = decltype(bufc)::value;
+        const float *kt = KT + BUF * KT_FLOATS;
+        const int row0 = j * ss * HROWS;
+        // ---- U tile: acc[rb][e] = mk[row] . qk[q] - |mk[row]|^2 / 2, row = row0 + 16 rb + 4 g + e, q = q0 + col
+        // first fragments right behind the barrier; their LDS latency hides behind the staging work below
+        f32x4 acc[4], fa[2][4];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+            fa[0][rb] = *reinterpret_cast<const f32x4 *>(kt + a_off[0] + rb * 1024);
+            acc[rb] = *reinterpret_cast<const f32x4 *>(kt + m_off + rb * 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // tile j+1 (loaded a step ago) -> the buffer whose readers finished before the previous barrier; tile j+2 -> registers
+        // (unconditional: past the chunk they move zeros / an unused tile)
+        sstore(KT + (BUF ^ 1) * KT_FLOATS);
+        gload((j + 2) * ss);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            const int cur = kb & 1;
+            if (kb < 3) {                                                // next fragments in flight under this block's 16 MFMAs
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb)
+                    fa[cur ^ 1][rb] = *reinterpret_cast<const f32x4 *>(kt + a_off[kb + 1] + rb * 1024);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb)
+                    acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[cur][rb][e], bq[kb][e], acc[rb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (row0 + HROWS > N) {                                          // ragged last step: rows beyond the bank never win
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (row0 + rb * 16 + 4 * g + e >= N) acc[rb][e] = -__builtin_inff();
+        }
+        if (!COLLECT) {
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) gm[rb][e] = fmaxf(gm[rb][e], acc[rb][e]);
+        } else {
+            // Optimistic appends, one accumulator register at a time and only where some lane of the wave passes its
+            // threshold (a compare + a scalar branch otherwise): take a list position with an LDS atomic, store if it is
+            // inside the list.  An append that finds its list full is remembered in `drop` and replayed after the list has
+            // been cut back to its best TOPK (which also raises that query's threshold): no overflow check on the way.
+            unsigned drop = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float v = acc[i >> 2][i & 3];
+                const bool h = v > tcol;
+                if (__ballot(h)) {
+                    if (h) {
+                        const int p = atomicAdd(&CNT[col], 1);
+                        if (p < CAP2) {
+                            LV[l_off + p] = v;
+                            LI[l_off + p] = row0 + (i >> 2) * 16 + 4 * g + (i & 3);
+                        } else {
+                            drop |= 1u << i;
+                        }
+                    }
+                }
+            }
+            while (__ballot(drop != 0)) {                                // rare: adversarial orderings, massive ties
+                const unsigned long long dl = __ballot(drop != 0);
+                unsigned fq = (unsigned)((dl | (dl >> 16) | (dl >> 32) | (dl >> 48)) & 0xffffull);
+                lds_fence();
+                while (fq) {                                             // a list with drops holds exactly CAP2 entries
+                    const int jj = __builtin_ctz(fq);
+                    fq &= fq - 1;
+                    const float tt = wave_select128(LV + jj * CAP2, LI + jj * CAP2, CAP2, lane);
+                    if (lane == 0) { CNT[jj] = TOPK; TAU[jj] = fmaxf(TAU[jj], tt); }
+                    lds_fence();
+                }
+                tcol = TAU[col];
+                unsigned again = 0;
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (((drop >> i) & 1u) && acc[i >> 2][i & 3] > tcol) {
+                        const int p = atomicAdd(&CNT[col], 1);
+                        if (p < CAP2) {
+                            LV[l_off + p] = acc[i >> 2][i & 3];
+                            LI[l_off + p] = row0 + (i >> 2) * 16 + 4 * g + (i & 3);
+                        } else {
+                            again |= 1u << i;
+                        }
+                    }
+                drop = again;
+            }
+        }
+        __syncthreads();
+    };
+    {
+        using B0 = std::integral_constant<int, 0>;
+        using B1 = std::integral_constant<int, 1>;
+        int j = j0;
+        for (; j + 1 < j1; j += 2) {
+            step(j, B0{});
+            step(j + 1, B1{});
+        }
+        if (j < j1) step(j, B0{});
+    }
+    if (q0 >= Q) return;
+    if (!COLLECT) {
+        if (q0 + col < Q) {
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    gmax[((long)chunk * NGRP2 + 16 * g + 4 * rb + e) * Q + q0 + col] = 0.25f * gm[rb][e];
+        }
+        return;
+    }
+    // chunk winners -> global: cand_n[chunk][q] entries of cand_v / cand_i[chunk][q][TOPK]
+    lds_fence();
+    for (int jj = 0; jj < 16; ++jj) {
+        float *lv = LV + jj * CAP2;
+        int *li = LI + jj * CAP2;
+        int cnt = __builtin_amdgcn_readfirstlane(CNT[jj]);
+        if (cnt > TOPK) { wave_select128(lv, li, cnt, lane); cnt = TOPK; }
+        lds_fence();
+        const int q = q0 + jj;
+        if (q < Q) {
+            const long o = ((long)chunk * Q + q) * TOPK + lane;
+            if (lane < cnt) { cand_v[o] = 0.25f * lv[lane]; cand_i[o] = li[lane]; }
+            if (lane == 0) cand_n[(long)chunk * Q + q] = cnt;
+        }
+    }
+}
+
+// pass 1 of the fusion attention read (exact column maxima need every row): one wave = 16 queries, fragments straight
+// from global/L2 (T = 1 memory: 1620 rows, a few microseconds)
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void colmax_pass_kernel(
+    const float *__restrict__ mk, const float *__restrict__ msq, const float *__restrict__ qk, int N, int Q,
+    int steps_per_chunk, float *__restrict__ gmax) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q0 = (blockIdx.x * WAVES + wave) * 16;
-    if (q0 >= Q) return;                                                // wave-uniform; no block barriers below
+    if (q0 >= Q) return;
     const int chunk = blockIdx.y;
     const int nsteps = (N + HROWS - 1) / HROWS;
     const int h0 = chunk * steps_per_chunk;
     const int h1 = min(nsteps, h0 + steps_per_chunk);
     const int g = lane >> 4, col = lane & 15;
-    const int qcol = min(q0 + col, Q - 1);
-
     f32x4 bq[4];
     load_bq(qk, Q, q0, lane, bq);
-    float tcol = -__builtin_inff();
-    f32x4 gm = {tcol, tcol, tcol, tcol};                                // pass 1: maxima per row block rb
-    if (COLLECT) {
-        tcol = tau_in[qcol];
-        if (lane < 16) { CNT[lane] = 0; TAU[lane] = tcol; }
-        lds_fence();
-    }
-
-    HalfFrag cur, nxt;
-    if (h0 < h1) load_half(mk, msq, N, h0 * HROWS, lane, cur);
+    const float ninf = -__builtin_inff();
+    f32x4 gm = {ninf, ninf, ninf, ninf};
     for (int h = h0; h < h1; ++h) {
         const int row0 = h * HROWS;
-        // prefetch the next step's fragments under this step's MFMAs (clamped re-load on the last step)
-        load_half(mk, msq, N, min(h + 1, h1 - 1) * HROWS, lane, nxt);
+        HalfFrag cur;
+        load_half(mk, msq, N, row0, lane, cur);
         f32x4 acc[4];
         mfma_half(cur, bq, acc);
         const bool tail = row0 + HROWS > N;
-        if (!COLLECT) {
 #pragma unroll
-            for (int rb = 0; rb < 4; ++rb)
+        for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float v = (tail && row0 + rb * 16 + 4 * g + j >= N) ? -__builtin_inff() : acc[rb][j];
-                    gm[rb] = fmaxf(gm[rb], v);
-                }
-        } else {
-            bool hit = false;
-#pragma unroll
-            for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    hit |= (acc[rb][j] > tcol) && !(tail && row0 + rb * 16 + 4 * g + j >= N);
-            if (__ballot(hit)) {                                        // rare once tau is global
-                // make room: any list that could overflow in this step is cut back to its best TOPK
-                const int cn = CNT[col];
-                unsigned long long full = __ballot(cn > CAP - HROWS);
-                unsigned fq = (unsigned)((full | (full >> 16) | (full >> 32) | (full >> 48)) & 0xffffull);
-                while (fq) {
-                    const int j = __builtin_ctz(fq);
-                    fq &= fq - 1;
-                    const int c = __builtin_amdgcn_readfirstlane(CNT[j]);
-                    const float t = wave_select128(LV + j * CAP, LI + j * CAP, c, lane);
-                    if (lane == 0) { CNT[j] = TOPK; TAU[j] = fmaxf(TAU[j], t); }
-                    lds_fence();
-                }
-                tcol = TAU[col];
-                if (hit) {
-#pragma unroll
-                    for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const int row = row0 + rb * 16 + 4 * g + j;
-                            if (acc[rb][j] > tcol && row < N) {
-                                const int p = atomicAdd(&CNT[col], 1);
-                                LV[col * CAP + p] = acc[rb][j];
-                                LI[col * CAP + p] = row;
-                            }
-                        }
-                }
-                lds_fence();
+            for (int j = 0; j < 4; ++j) {
+                const float v = (tail && row0 + rb * 16 + 4 * g + j >= N) ? ninf : acc[rb][j];
+                gm[rb] = fmaxf(gm[rb], v);
             }
-        }
-        cur = nxt;
     }
-    if (!COLLECT) {
-        if (q0 + col < Q) {
+    if (q0 + col < Q) {
 #pragma unroll
-            for (int rb = 0; rb < 4; ++rb) gmax[((long)chunk * NGRP + 4 * g + rb) * Q + q0 + col] = gm[rb];
-        }
-        return;
-    }
-    // chunk winners -> global: cand[chunk][q][TOPK] (missing entries = -inf)
-    lds_fence();
-    for (int j = 0; j < 16; ++j) {
-        float *lv = LV + j * CAP;
-        int *li = LI + j * CAP;
-        int cnt = __builtin_amdgcn_readfirstlane(CNT[j]);
-        if (cnt > TOPK) { wave_select128(lv, li, cnt, lane); cnt = TOPK; }
-        lds_fence();
-        const int q = q0 + j;
-        if (q < Q && lane < TOPK) {
-            const long o = ((long)chunk * Q + q) * TOPK + lane;
-            cand_v[o] = lane < cnt ? lv[lane] : -__builtin_inff();
-            cand_i[o] = lane < cnt ? li[lane] : 0;
-        }
+        for (int rb = 0; rb < 4; ++rb) gmax[((long)chunk * NGRP + 4 * g + rb) * Q + q0 + col] = gm[rb];
     }
 }
 
-// tau[q] = TOPK-th largest of the G = NC*NGRP group maxima of query q (-inf when fewer than TOPK are finite)
+// tau[q] = TOPK-th largest of the G group maxima of query q (-inf when fewer than TOPK are finite); G <= 512
 __global__ __launch_bounds__(256) void threshold_kernel(const float *__restrict__ gmax, int G, int Q,
                                                         float *__restrict__ tau) {
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= Q) return;
-    unsigned k[4];
+    unsigned k[8];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < 8; ++e) {
         const int gi = lane + 64 * e;
         const float v = gi < G ? gmax[(long)gi * Q + q] : -__builtin_inff();
         k[e] = v > -__builtin_inff() ? f2key(v) : 0u;
@@ -243,8 +393,9 @@ __global__ __launch_bounds__(256) void threshold_kernel(const float *__restrict_
     unsigned prefix = 0;
     for (int bit = 31; bit >= 0; --bit) {
         const unsigned cand = prefix | (1u << bit);
-        const int c = __popcll(__ballot(k[0] >= cand)) + __popcll(__ballot(k[1] >= cand)) +
-                      __popcll(__ballot(k[2] >= cand)) + __popcll(__ballot(k[3] >= cand));
+        int c = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) c += __popcll(__ballot(k[e] >= cand));
         if (c >= TOPK) prefix = cand;
     }
     // prefix == 0: fewer than TOPK finite maxima -> no usable bound.  The bound must stay BELOW the
@@ -252,14 +403,16 @@ __global__ __launch_bounds__(256) void threshold_kernel(const float *__restrict_
     if (lane == 0) tau[q] = prefix == 0u ? -__builtin_inff() : key2f(prefix - 1u);
 }
 
-// one wave per query: merge NC*50 chunk winners, softmax, sparse readout
+// one wave per query: merge the chunk lists (cand_n[c][q] entries each; cand_n == nullptr: TOPK each, -inf = missing),
+// softmax, sparse readout
 __global__ __launch_bounds__(256) void merge_readout_kernel(const float *__restrict__ cand_v,
-                                                            const int32_t *__restrict__ cand_i, int NC, int Q,
+                                                            const int32_t *__restrict__ cand_i,
+                                                            const int32_t *__restrict__ cand_n, int NC, int Q,
                                                             const float *__restrict__ mv, long mv_os, int k,
                                                             float *__restrict__ readout, long ro_os,
                                                             int32_t *__restrict__ topk_idx, float *__restrict__ topk_w) {
-    __shared__ float s_v[4][MAXCHUNK * TOPK];
-    __shared__ int s_i[4][MAXCHUNK * TOPK];
+    __shared__ float s_v[4][MAXCHUNK2 * TOPK];
+    __shared__ int s_i[4][MAXCHUNK2 * TOPK];
     __shared__ float s_w[4][64];
     __shared__ int s_x[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -267,12 +420,19 @@ __global__ __launch_bounds__(256) void merge_readout_kernel(const float *__restr
     if (q >= Q) return;
     float *sv = s_v[wave];
     int *si = s_i[wave];
-    const int n = NC * TOPK;
-    for (int e = lane; e < n; e += 64) {
-        const int c = e / TOPK, j = e - c * TOPK;
-        const long o = ((long)c * Q + q) * TOPK + j;
-        sv[e] = cand_v[o];
-        si[e] = cand_i[o];
+    // list sizes -> offsets (lane c owns chunk c; NC <= 64), then all entries with independent loads
+    int nl = lane < NC ? (cand_n ? cand_n[(long)lane * Q + q] : TOPK) : 0;
+    int ol = nl;
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(ol, o); if (lane >= o) ol += u; }
+    const int n = __shfl(ol, 63);
+    ol -= nl;
+    for (int c = 0; c < NC; ++c) {
+        const int nc = __shfl(nl, c), oc = __shfl(ol, c);
+        if (lane < nc) {
+            const long o = ((long)c * Q + q) * TOPK + lane;
+            sv[oc + lane] = cand_v[o];
+            si[oc + lane] = cand_i[o];
+        }
     }
     lds_fence();
     // bitwise radix select of the TOPK-th largest key over n entries
@@ -339,47 +499,51 @@ __global__ __launch_bounds__(256) void merge_readout_kernel(const float *__restr
     }
 }
 
-int memread_num_chunks(int N) {
-    const int steps = (N + HROWS - 1) / HROWS;
-    return steps < MAXCHUNK ? steps : MAXCHUNK;
+MemReadPlan memread_plan(int N, int Q) {
+    MemReadPlan p;
+    p.steps = (N + HROWS - 1) / HROWS;
+    const int qblocks = (Q + 63) / 64;
+    // pass 1 samples every ss-th step: at least ~48 sampled steps so that the 64 * nc1 row groups are all populated
+    static const int ss_env = [] { const char *e = getenv("STCN_MEMREAD_SAMPLE"); return e ? atoi(e) : 0; }();
+    p.ss = ss_env > 0 ? ss_env : (p.steps >= 768 ? 8 : (p.steps >= 192 ? 4 : (p.steps >= 96 ? 2 : 1)));
+    p.ns = (p.steps + p.ss - 1) / p.ss;
+    // chunks: as many as keep qblocks * nc within ONE round of co-resident workgroups (a few workgroups beyond the round
+    // would run alone afterwards and double the time): pass 2 holds 2 workgroups per CU (LDS lists), pass 1 up to 4
+    auto chunks = [&](int steps, int resident, int hi, int *spc) {
+        int nc = resident / qblocks;
+        nc = nc < 1 ? 1 : (nc > hi ? hi : nc);
+        nc = nc > steps ? steps : nc;
+        *spc = (steps + nc - 1) / nc;
+        return (steps + *spc - 1) / *spc;
+    };
+    p.nc1 = chunks(p.ns, 1024, MAXCHUNK1, &p.spc1);         // 64 maxima per chunk and query: <= 512 for threshold_kernel
+    p.nc2 = chunks(p.steps, 512, MAXCHUNK2, &p.spc2);
+    return p;
 }
+// bound of nc * Q over both passes: nc1 <= min(8, 1024 / qblocks) and nc2 <= max(1, 512 / qblocks) with Q <= 64 qblocks
+size_t memread_list_pairs(int Q) { return (size_t)65536 + (size_t)Q + 64; }
 
 void memory_read_launch(const float *mk, const float *msq, const float *qk, int N, int Q, const float *mv,
                         long mv_os, int k, float *readout, long ro_os, int32_t *topk_idx, float *topk_w,
                         MemReadScratch scr, hipStream_t s) {
-    constexpr int WAVES = 4;
-    const int steps = (N + HROWS - 1) / HROWS;
-    const int qblocks = (Q + 16 * WAVES - 1) / (16 * WAVES);
-    // chunks: >= 4 so that G = 16*NC >= 64 group maxima exist (tight, valid threshold), and enough
-    // workgroups to cover the 256 CUs a few times over
-    int NC = (768 + qblocks - 1) / qblocks;
-    if (NC < 4) NC = 4;
-    if (NC > MAXCHUNK) NC = MAXCHUNK;
-    if (NC > steps) NC = steps;
-    const int spc = (steps + NC - 1) / NC;
-    const int NCeff = (steps + spc - 1) / spc;
-    const size_t lds2 = (size_t)WAVES * (2 * 16 * CAP + 32) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&affinity_pass_kernel<WAVES, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-        attr_set = true;
-    }
-    const dim3 grid(qblocks, NCeff);
-    float *gmax = scr.gmax, *tau = scr.tau;
-    hipLaunchKernelGGL((affinity_pass_kernel<WAVES, false>), grid, dim3(64 * WAVES), 0, s, mk, msq, qk, N, Q, spc, gmax,
-                       (const float *)nullptr, (float *)nullptr, (int32_t *)nullptr);
-    hipLaunchKernelGGL(threshold_kernel, dim3((Q + 3) / 4), dim3(256), 0, s, gmax, NCeff * NGRP, Q, tau);
-    hipLaunchKernelGGL((affinity_pass_kernel<WAVES, true>), grid, dim3(64 * WAVES), lds2, s, mk, msq, qk, N, Q, spc,
-                       (float *)nullptr, tau, scr.cand_v, scr.cand_i);
-    hipLaunchKernelGGL(merge_readout_kernel, dim3((Q + 3) / 4), dim3(256), 0, s, scr.cand_v, scr.cand_i, NCeff, Q,
+    const MemReadPlan pl = memread_plan(N, Q);
+    const int qblocks = (Q + 63) / 64;
+    const size_t lds1 = (size_t)2 * KT_FLOATS * sizeof(float);
+    const size_t lds2 = lds1 + (size_t)4 * LISTS_PER_WAVE * sizeof(float);
+    allow_big_lds(reinterpret_cast<const void *>(&affinity_tile_kernel<true>), lds2);
+    hipLaunchKernelGGL((affinity_tile_kernel<false>), dim3(qblocks, pl.nc1), dim3(256), lds1, s, mk, msq, qk, N, Q, pl.ns, pl.ss,
+                       pl.spc1, scr.gmax, (const float *)nullptr, (float *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
+    hipLaunchKernelGGL(threshold_kernel, dim3((Q + 3) / 4), dim3(256), 0, s, scr.gmax, pl.nc1 * NGRP2, Q, scr.tau);
+    hipLaunchKernelGGL((affinity_tile_kernel<true>), dim3(qblocks, pl.nc2), dim3(256), lds2, s, mk, msq, qk, N, Q, pl.steps, 1,
+                       pl.spc2, (float *)nullptr, scr.tau, scr.cand_v, scr.cand_i, scr.cand_n);
+    hipLaunchKernelGGL(merge_readout_kernel, dim3((Q + 3) / 4), dim3(256), 0, s, scr.cand_v, scr.cand_i, scr.cand_n, pl.nc2, Q,
                        mv, mv_os, k, readout, ro_os, topk_idx, topk_w);
 }
 
 void merge_only_launch(const float *cand_v, const int32_t *cand_i, int NC, int Q, const float *mv, long mv_os, int k,
                        float *readout, long ro_os, hipStream_t s) {
-    hipLaunchKernelGGL(merge_readout_kernel, dim3((Q + 3) / 4), dim3(256), 0, s, cand_v, cand_i, NC, Q, mv, mv_os, k,
-                       readout, ro_os, (int32_t *)nullptr, (float *)nullptr);
+    hipLaunchKernelGGL(merge_readout_kernel, dim3((Q + 3) / 4), dim3(256), 0, s, cand_v, cand_i, (const int32_t *)nullptr, NC, Q,
+                       mv, mv_os, k, readout, ro_os, (int32_t *)nullptr, (float *)nullptr);
 }
 
 // one wave per query, no LDS: 50 rows x 2 KB gathered with 16-byte loads (same pattern as merge_readout's gather)
@@ -576,8 +740,7 @@ void attention_read_launch(const float *mk, const float *msq, const float *qk, c
     const int spc = (steps + NC - 1) / NC;
     const int NCeff = (steps + spc - 1) / spc;
     const dim3 grid(qblocks, NCeff);
-    hipLaunchKernelGGL((affinity_pass_kernel<WAVES, false>), grid, dim3(64 * WAVES), 0, s, mk, msq, qk, hw, hw, spc,
-                       scr.gmax, (const float *)nullptr, (float *)nullptr, (int32_t *)nullptr);
+    hipLaunchKernelGGL((colmax_pass_kernel<WAVES>), grid, dim3(64 * WAVES), 0, s, mk, msq, qk, hw, hw, spc, scr.gmax);
     hipLaunchKernelGGL(colmax_kernel, dim3((hw + 255) / 256), dim3(256), 0, s, scr.gmax, NCeff * NGRP, hw, scr.cmax);
     hipLaunchKernelGGL((attention_pass_kernel<WAVES>), grid, dim3(64 * WAVES), 0, s, mk, msq, qk, hw, hw, spc, scr.cmax,
                        pooled, nch, scr.part);

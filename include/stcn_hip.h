@@ -130,6 +130,12 @@ int stcn_test_encode_value(const stcn_model *m, void *stream, const float *img, 
 int stcn_test_memory_read(void *stream, const float *mk, const float *mv, const float *qk,
                           int N, int Q, int k, int32_t *topk_idx, float *topk_w, float *readout);
 
+/* Measurement hook of the same read: `iters` whole reads on caller-provided device data between two HIP events on
+ * `stream` (scratch allocated outside the timed region); *ms = average per read; plan7 (may be NULL) receives the launch
+ * plan {steps, pass-1 sample stride, sampled steps, pass-1 chunks, steps per chunk, pass-2 chunks, steps per chunk}. */
+int stcn_bench_memory_read(void *stream, const float *mk, const float *mv, const float *qk, int N, int Q, int k,
+                           int iters, float *readout, float *ms, int32_t *plan7);
+
 /* Decoder + sigmoid + soft aggregation (prop_net.py:13-30,189-192; aggregate.py:22-37).
  * readout [k,hw16,512], f16_thin/f8/f4 NHWC -> logit4 [k,hw4] (may be NULL), agg [k+1,nh*nw]. */
 int stcn_test_decode(const stcn_model *m, void *stream, const float *readout, const float *f16_thin,

@@ -1,0 +1,47 @@
+"""GPU: bench.py's launch contract.  `python bench.py --gpus N` must start N ranks by itself (the driver's 1-GPU form has no
+torch.distributed.run around it); on this 1-GPU box both ranks share device 0 and the collectives run over gloo
+(STCN_BENCH_DEVICE / STCN_BENCH_BACKEND exist for exactly this test).  Reference sharding being mirrored: one process
+per --min-idx/--max-idx slice (eval_annotation_method.py:34-35,118-119)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+SMALL = ["--steps", "2", "--warmup", "0", "--frames", "12", "--height", "240", "--width", "432", "--streams", "1",
+         "--no-profile", "--no-f16x3-leg", "--no-r2", "--cpu-frames", "0", "--no-config3", "--no-memread-roofline"]
+
+
+def run_bench(args, env_extra=None):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    env.pop("LOCAL_RANK", None)
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_gpus_flag_launches_that_many_ranks():
+    one = run_bench(["--gpus", "1"] + SMALL)
+    assert one["n_gpus"] == 1 and one["value"] > 0 and len(one["jf_rows_rank_J_F_JF"]) == 1
+    assert one["config"]["sharding"] == "videos x1"
+    two = run_bench(["--gpus", "2"] + SMALL, {"STCN_BENCH_DEVICE": "0", "STCN_BENCH_BACKEND": "gloo"})
+    assert two["n_gpus"] == 2 and two["steps"] == 2
+    rows = two["jf_rows_rank_J_F_JF"]
+    assert [int(r[0]) for r in rows] == [0, 1], "one gathered J&F row per rank"
+    # same clip, same weights on both ranks -> identical J&F; and the same as the single-rank run
+    assert rows[0][1:] == rows[1][1:] == one["jf_rows_rank_J_F_JF"][0][1:]
+    # whole-job value = frames of ALL ranks / max time: 2 ranks x 2 videos x 11 frames
+    frames = two["value"] * two["ms_per_step"] * 1e-3 * two["steps"]
+    assert abs(frames - 2 * 2 * 11) < 1e-6 * frames + 1e-3
+    assert two["cpu_baseline"] is None and "rank 0 at N=1" in two["cpu_baseline_note"]
+    assert two["concurrent_videos_bit_identical"]
