@@ -15,7 +15,12 @@ Output: ONE JSON line on rank 0 (see the task contract) with two extra objects:
                  timed region / their summed device time (HIP events on the engine stream) vs the
                  fp32 MFMA peak 157.3 TFLOP/s (MI355X_MICROARCH.md).
   cpu_baseline - the CPU oracle (oracle/stcn_oracle.py, a port validated against the reference) timed on
-                 this box's host cores on a bounded sample of the same workload.
+                 this box's host cores on a bounded sample of BASELINE config 1 (both rounds), rank 0 at N=1 only.
+Further objects (not the headline): roofline_memread (the space-time memory read at config-3 scale, MFMA fraction on
+2*N*Q*64 and GB/s on SURVEY 8(d)'s algorithmic bytes), config3 (k=5, mem_freq=1, T=104: the full-bank multi-object
+case), extra_f16x3_leg, r2_frames_per_s_rank0.  Real data: when ./model_weights/mivos/{stcn,fusion}.pth and
+./data/DAVIS_17 exist the same line is measured on real DAVIS-17-val clips with "data": "real" (there is no network
+here, so the default is the synthetic recipe and the line says so).
 """
 from __future__ import annotations
 
@@ -44,7 +49,17 @@ def parse():
     ap.add_argument("--width", type=int, default=854)
     ap.add_argument("--mem-freq", type=int, default=5)
     ap.add_argument("--objects", type=int, default=1, help="k>1: multi-object engine via the scribble/(k+1)-channel path (config 3)")
-    ap.add_argument("--cpu-frames", type=int, default=40, help="frames of the bounded CPU-oracle sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=41,
+                    help="frames of the bounded CPU-oracle sample: BASELINE config 1 is T=82, interact(0) then interact(41); the default "
+                         "runs the same two rounds on a T=41 clip (interact(0), interact(20)); 82 = the full config; 0 = skip")
+    ap.add_argument("--no-config3", dest="config3", action="store_false",
+                    help="skip the extra config-3 leg (k=5 objects, mem_freq=1, T=104: full-length bank)")
+    ap.add_argument("--config3-frames", type=int, default=104)
+    ap.add_argument("--config3-objects", type=int, default=5)
+    ap.add_argument("--no-memread-roofline", dest="memread_roofline", action="store_false",
+                    help="skip the memory-read roofline leg (stcn_bench_memory_read at config-3 bank sizes)")
+    ap.add_argument("--data", choices=("auto", "synthetic", "real"), default="auto",
+                    help="auto: real DAVIS-17 val clips + checkpoints when present on the box, else synthetic")
     ap.add_argument("--no-profile", action="store_true", help="skip the roofline leg (roofline = null)")
     ap.add_argument("--roof-steps", type=int, default=1, help="videos of the profiled single-stream roofline leg")
     ap.add_argument("--streams", type=int, default=3, help="videos in flight per GPU (one host thread + HIP stream each)")
@@ -56,17 +71,19 @@ def parse():
 
 
 def cpu_baseline(psd, fsd, H, W, frames, mem_freq):
-    """Oracle (kind 'port') on the host cores: interact(mask, 0) on a `frames`-long clip of the same shape."""
+    """Oracle (kind 'port') on the host cores, BASELINE config 1's two rounds on a `frames`-long clip of the same shape:
+    R1 = interact(mask, 0) on a fresh core, R2 = interact(mask, frames // 2) (cached keys, fusion between the two frames)."""
     from eva_vos_amd import synth
     from oracle.stcn_oracle import OracleCore
     from oracle import stcn_oracle as O
     img, msk = synth.synthetic_clip(frames, H, W), synth.synthetic_mask(frames, H, W, 1)
     # pick the intra-op thread count that is fastest on this host (hundreds of threads thrash on the
     # small GEMMs of the path): one key-encoder pass per candidate
+    host_cores = os.cpu_count() or 1
     fw = O.fold_bn(psd)
     x0, _ = O.pad16(img[:, 0])
     best_t, best = 1, float("inf")
-    for nt in sorted({n for n in (8, 16, 32, 64, os.cpu_count() or 1) if n <= (os.cpu_count() or 1)}):
+    for nt in sorted({n for n in (8, 16, 32, 64, host_cores) if n <= host_cores}):
         torch.set_num_threads(nt)
         t0 = time.perf_counter()
         O.encode_key(fw, x0)
@@ -75,31 +92,149 @@ def cpu_baseline(psd, fsd, H, W, frames, mem_freq):
             best_t, best = nt, el
     torch.set_num_threads(best_t)
     core = OracleCore(psd, fsd, img, 1, mem_freq=mem_freq)
+    mid = frames // 2
     t0 = time.perf_counter()
-    ref_masks = core.interact(msk[:, 0], 0)
-    dt = time.perf_counter() - t0
-    base = dict(value=(frames - 1) / dt, unit="frames/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"oracle OracleCore.interact(mask,0) on a {frames}-frame {H}x{W} synthetic clip "
-                       f"({frames - 1} propagated frames, {dt:.1f} s, torch {torch.__version__} CPU)")
-    return base, (img, msk, ref_masks)
+    ref1 = core.interact(msk[:, 0], 0).copy()
+    t1 = time.perf_counter()
+    ref2 = core.interact(msk[:, mid], mid).copy()
+    t2 = time.perf_counter()
+    n1, n2 = frames - 1, frames - 1
+    base = dict(value=n1 / (t1 - t0), unit="frames/s", cores=best_t, kind="port", host_cores=host_cores, threads=best_t,
+                r1_frames_per_s=n1 / (t1 - t0), r2_frames_per_s=n2 / (t2 - t1), torch=torch.__version__,
+                sample=f"oracle OracleCore on a {frames}-frame {H}x{W} synthetic clip, k=1, mem_freq={mem_freq} (BASELINE config 1 is "
+                       f"T=82): R1 interact(mask,0) {n1} frames in {t1 - t0:.1f} s, R2 interact(mask,{mid}) {n2} frames in "
+                       f"{t2 - t1:.1f} s; {best_t} intra-op threads (fastest of 8/16/32/64/all) on {host_cores} host cores; "
+                       f"value = R1")
+    return base, (img, msk, ref1, ref2)
 
 
 def parity_vs_oracle(prop, fuse, sample, mem_freq):
-    """The HIP engine on the clip the CPU oracle just processed: mask IoU between the two and J&F of each against the
-    synthetic ground truth (north_star: masks within 1e-3 IoU, J&F within 0.1 of the CPU reference)."""
+    """The HIP engine on the clip the CPU oracle just processed, both rounds: mask IoU between the two, frames/s of the same
+    two interactions on the GPU (one video in flight), and J&F of each against the synthetic ground truth - the CPU masks
+    scored by the CPU restatement of interactions/metrics.py, the HIP masks by the HIP J/F kernel (north_star: masks within
+    1e-3 IoU, J&F within 0.1 of the CPU reference)."""
     from eva_vos_amd import metrics
     from mivos.inference_core import InferenceCore
-    img, msk, ref_masks = sample
-    got = InferenceCore(prop, fuse, img.cuda(), 1, mem_freq=mem_freq).interact(msk[:, 0], 0)
-    a, b = got > 0, ref_masks > 0
-    union = (a | b).sum()
-    gt = (msk[0, :, 0] > 0.5).cuda()
-    jf_gpu = metrics.sequence_scores_gpu(gt, torch.from_numpy(a).cuda())[1:, 2].mean()
-    jf_cpu = metrics.sequence_scores_gpu(gt, torch.from_numpy(b).cuda())[1:, 2].mean()
-    return dict(clip=f"{img.shape[1]} frames {img.shape[-2]}x{img.shape[-1]} (the cpu_baseline sample)",
-                mask_iou_hip_vs_cpu_oracle=float((a & b).sum() / union) if union else 1.0,
-                mask_pixels_differing=int((a != b).sum()), mask_pixels_total=int(a.size),
-                j_and_f_hip=float(jf_gpu), j_and_f_cpu_oracle=float(jf_cpu))
+    img, msk, ref1, ref2 = sample
+    mid = img.shape[1] // 2
+    core = InferenceCore(prop, fuse, img.cuda(), 1, mem_freq=mem_freq)
+    core.interact(msk[:, 0], 0)                         # warm-up (allocations, first-launch costs), then a fresh state
+    core.reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    got1 = core.interact(msk[:, 0], 0).copy()
+    t1 = time.perf_counter()
+    got2 = core.interact(msk[:, mid], mid).copy()
+    t2 = time.perf_counter()
+    gt_np = msk[0, :, 0].numpy() > 0.5
+    gt = torch.from_numpy(gt_np).cuda()
+    out = dict(clip=f"{img.shape[1]} frames {img.shape[-2]}x{img.shape[-1]} (the cpu_baseline sample)",
+               hip_r1_frames_per_s=(img.shape[1] - 1) / (t1 - t0), hip_r2_frames_per_s=(img.shape[1] - 1) / (t2 - t1))
+    for tag, got, ref in (("r1", got1, ref1), ("r2", got2, ref2)):
+        a_, b_ = got > 0, ref > 0
+        union = (a_ | b_).sum()
+        out[f"mask_iou_hip_vs_cpu_oracle_{tag}"] = float((a_ & b_).sum() / union) if union else 1.0
+        out[f"mask_pixels_differing_{tag}"] = int((a_ != b_).sum())
+    out["mask_pixels_total"] = int(got1.size)
+    # interacted frames carry no propagated mask (the callers overwrite them): score the others
+    keep = np.ones(img.shape[1], bool)
+    keep[[0, mid]] = False
+    out["j_and_f_hip"] = float(metrics.sequence_scores_gpu(gt, torch.from_numpy(got2 > 0).cuda())[keep, 2].mean())
+    out["j_and_f_cpu_oracle"] = float(metrics.sequence_scores(gt_np, ref2 > 0)[keep, 3].mean())
+    out["j_and_f_scorers"] = "hip: stcn_metrics_jf_counts kernel; cpu_oracle: eva_vos_amd.metrics (NumPy restatement of interactions/metrics.py)"
+    return out
+
+
+def memread_roofline(k, hw16=1620):
+    """The space-time memory read alone at config-3 bank sizes (T = 52 and 104 frames in the bank, k objects, one frame of
+    queries), timed with HIP events around whole reads (pass 1 + threshold + pass 2 + merge/gather) by the C-ABI hook
+    stcn_bench_memory_read.  Units: algorithmic FLOP 2*N*Q*64 (the affinity; the 50-sparse readout adds
+    2*k*Q*50*512), algorithmic bytes = keys N*65*4 once + queries + 50 gathered value rows of 2 KB per query and object
+    + the readout."""
+    import ctypes as C
+    from eva_vos_amd import _lib
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(0)
+    rows = []
+    for T in (52, 104):
+        N, Q = T * hw16, hw16
+        mk = (torch.randn(N, 64, generator=g) * 0.8).cuda()
+        qk = (torch.randn(Q, 64, generator=g) * 0.8).cuda()
+        mv = torch.randn(k, N, 512, generator=g).cuda()
+        ro = torch.empty(k, Q, 512, device="cuda")
+        ms, plan = C.c_float(), (C.c_int32 * 7)()
+        _lib.check(lib.stcn_bench_memory_read(C.c_void_p(torch.cuda.current_stream().cuda_stream), C.c_void_p(mk.data_ptr()),
+                                              C.c_void_p(mv.data_ptr()), C.c_void_p(qk.data_ptr()), N, Q, k, 10,
+                                              C.c_void_p(ro.data_ptr()), C.byref(ms), plan))
+        fl = 2.0 * N * Q * 64
+        by = 4.0 * (N * 65 + Q * 64 + k * Q * 50 * 512 + k * Q * 512)
+        tf = fl / (ms.value * 1e-3) / 1e12
+        rows.append(dict(bank_frames=T, N=N, Q=Q, k=k, ms_per_read=ms.value, affinity_tflops=tf, mfma_frac=tf / FP32_MFMA_PEAK_TFLOPS,
+                         algorithmic_gbytes_per_s=by / (ms.value * 1e-3) / 1e9, hbm_frac=by / (ms.value * 1e-3) / 8e12,
+                         pass1_sample_stride=int(plan[1])))
+        del mk, qk, mv, ro
+    full = rows[-1]
+    return {"bound": "mfma", "achieved": full["affinity_tflops"], "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": full["mfma_frac"], "traffic": None,
+            "kernel": "affinity_tile_kernel x2 (sampled pass 1 + pass 2, v_mfma_f32_16x16x4_f32) + threshold + merge_readout (gather)",
+            "what": f"whole read at T=104, k={k}: 2*N*Q*64 FLOP / time of all four kernels; HIP events around 10 reads; random N(0,0.8) keys",
+            "algorithmic_gbytes_per_s": full["algorithmic_gbytes_per_s"], "hbm_frac_of_8TBps": full["hbm_frac"], "by_bank_size": rows}
+
+
+def real_inputs(a):
+    """Checkpoints + the first DAVIS-17 val sample, or None when the box does not hold them (the usual case: no network)."""
+    wdir, root = os.path.join(ROOT, "model_weights", "mivos"), os.path.join(ROOT, "data", "DAVIS_17", "trainval")
+    imset = os.path.join(root, "ImageSets", "2017", "val.txt")
+    paths = [os.path.join(wdir, "stcn.pth"), os.path.join(wdir, "fusion.pth"), imset]
+    if not all(os.path.exists(q) for q in paths):
+        return None
+    from eva_vos_amd import fq_driver
+    ds = fq_driver.ClipDataset(root, imset)
+    smp = ds[0]
+    return dict(prop_sd=torch.load(paths[0], map_location="cpu"), fuse_sd=torch.load(paths[1], map_location="cpu"),
+                rgb=smp["rgb"], gt=smp["gt"], name=smp["name"])
+
+
+def config3_leg(prop, fuse, T, H, W, k):
+    """One video of BASELINE config 3 on a fresh engine: interact(mask, 0) with k objects, mem_freq = 1; a second, profiled
+    run (HIP events per launch class) gives the kernel-time shares and the conv / memory-read rates of this shape."""
+    from eva_vos_amd import synth
+    from mivos.inference_core import InferenceCore
+    img = synth.synthetic_clip(T, H, W).cuda()
+    gt = synth.synthetic_mask(T, H, W, k)
+    m0 = torch.cat([1 - gt[:, 0].sum(0, keepdim=True).clamp(0, 1), gt[:, 0]], 0)
+    la_saved = os.environ.get("STCN_LOOKAHEAD")
+    os.environ["STCN_LOOKAHEAD"] = "2"                      # one video in flight: key encoder ahead on a side stream
+    e = InferenceCore(prop, fuse, img, k, mem_freq=1)
+    e.interact(m0, 0, scribble=True)                       # warm-up
+    e.reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = e.interact(m0, 0, scribble=True)
+    dt = time.perf_counter() - t0
+    st = e.stats()
+    del e
+    os.environ["STCN_LOOKAHEAD"] = "0"
+    e = InferenceCore(prop, fuse, img, k, mem_freq=1)
+    e.set_profiling(True)
+    out2 = e.interact(m0, 0, scribble=True)
+    torch.cuda.synchronize()
+    prof = e.kernel_profile()
+    prof.pop("conv_hbm_bound")
+    del e
+    torch.cuda.empty_cache()
+    os.environ["STCN_LOOKAHEAD"] = la_saved if la_saved is not None else "2"
+    tot = sum(v["ms"] for v in prof.values())
+    conv, mr = prof["conv"], prof["memread"]
+    return {"workload": f"{H}x{W} {k}-object engine (scribble / (k+1)-channel path), mem_freq=1, T={T}: interact(mask,0) on a fresh engine; "
+                        f"bank grows to {st['bank_fwd']} frames = {st['bank_fwd'] * 1620} rows",
+            "frames_per_s": st["frames"] / dt, "ms_per_frame": 1e3 * dt / st["frames"], "frames": st["frames"], "value_encodes": st["value_enc"],
+            "repeat_bit_identical": bool(np.array_equal(out, out2)),
+            "object_pixels_fraction": float((out > 0).mean()),
+            "kernel_time_share": {c: round(v["ms"] / tot, 4) for c, v in prof.items() if v["ms"] > 0},
+            "conv_tflops": conv["flops"] / (conv["ms"] * 1e-3) / 1e12, "conv_frac_of_fp32_mfma_peak": conv["flops"] / (conv["ms"] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+            "memread_ms_per_frame": mr["ms"] / st["frames"], "memread_affinity_tflops": mr["flops"] / (mr["ms"] * 1e-3) / 1e12,
+            "memread_algorithmic_gbytes_per_s": mr["bytes"] / (mr["ms"] * 1e-3) / 1e9}
 
 
 def launch_ranks(n):
@@ -150,14 +285,26 @@ def main():
     from mivos.inference_core import InferenceCore
 
     prop, fuse = PropagationNetwork(), FusionNet()
-    psd, fsd = synth.recipe_state_dict(prop), synth.recipe_state_dict(fuse)
+    # Real weights / clips when the box has them (reference: eval_annotation_method.py:51-64 loads
+    # ./model_weights/mivos/{stcn,fusion}.pth and ./data/DAVIS_17); there is no network here, so the default is synthetic.
+    real = real_inputs(a) if a.data in ("auto", "real") else None
+    if a.data == "real" and real is None:
+        raise SystemExit("--data real: ./model_weights/mivos/{stcn,fusion}.pth and ./data/DAVIS_17/trainval are not on this box")
+    if real is not None:
+        psd, fsd = real["prop_sd"], real["fuse_sd"]
+    else:
+        psd, fsd = synth.recipe_state_dict(prop), synth.recipe_state_dict(fuse)
     prop.load_state_dict(psd)
     fuse.load_state_dict(fsd)
 
     T, H, W = a.frames, a.height, a.width
-    img = synth.synthetic_clip(T, H, W).cuda()
     K_OBJ = a.objects
-    gt = synth.synthetic_mask(T, H, W, K_OBJ)
+    if real is not None:
+        img, gt = real["rgb"].cuda(), real["gt"]                  # first val sample: [1,T,3,H,W], [1,T,1,H,W]
+        T, H, W, K_OBJ = img.shape[1], img.shape[-2], img.shape[-1], 1
+    else:
+        img = synth.synthetic_clip(T, H, W).cuda()
+        gt = synth.synthetic_mask(T, H, W, K_OBJ)
 
     def as_input(m):         # k == 1: [1,1,H,W] without bg row; k > 1: bg row first + scribble=True (reference semantics)
         return m.clone() if K_OBJ == 1 else torch.cat([1 - m.sum(0, keepdim=True).clamp(0, 1), m], 0)
@@ -177,7 +324,7 @@ def main():
     # of one engine must reproduce its previous result bit for bit while other clips run beside it.
     per_lane = 2
     def variant(n):          # clip 0 = the recipe clip; clip n = the same scene under its own seeded sensor noise
-        if n == 0:
+        if n == 0:                                  # (real data: clip n = the first val clip under that noise too)
             return img
         g = torch.Generator(device="cuda").manual_seed(1000 + n)
         return img + 0.15 * torch.randn(img.shape, generator=g, device="cuda")
@@ -189,6 +336,7 @@ def main():
             return InferenceCore(prop, fuse, clips[lane][j], K_OBJ, mem_freq=a.mem_freq)
 
     pool = [[make(l, j) for j in range(per_lane)] for l in range(S)]
+    pad_hw = (pool[0][0].nh, pool[0][0].nw)
     torch.cuda.synchronize()
     for i in range(a.warmup):
         l = i % S
@@ -305,6 +453,16 @@ def main():
         torch.cuda.synchronize()
         r2 = sum(r[0] for r in res2) / (time.perf_counter() - t1)
 
+    # Extra leg: BASELINE config 3 at its stated size - one multi-object engine (k objects through the scribble /
+    # (k+1)-channel path, the only multi-object path of the reference: inference_core.py:220-233), mem_freq = 1 (every
+    # frame enters the bank: full-length memory, bank rows up to T * 1620), T = 104 (the longest clip, download_data.py:42).
+    cfg3 = None
+    if a.config3 and world == 1 and real is None:
+        del pool, clips
+        torch.cuda.empty_cache()
+        cfg3 = config3_leg(prop, fuse, a.config3_frames, H, W, a.config3_objects)
+    mr_roof = memread_roofline(a.config3_objects) if (a.memread_roofline and world == 1) else None
+
     # whole-job numbers: max time over ranks, frames summed over ranks
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
@@ -328,14 +486,14 @@ def main():
             "ms_per_step": 1e3 * dt_all / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if os.environ.get("STCN_PRECISION") != "f16x3" else "f16x3 (fp16 hi/lo split operands, f32 accumulate)",
-            "data": "synthetic",
-            "config": {"workload": f"DAVIS-17-val-shaped {H}x{W} (padded {pool[0][0].nh}x{pool[0][0].nw}) {'single' if K_OBJ == 1 else K_OBJ}-object "
+            "data": "real" if real is not None else "synthetic",
+            "config": {"workload": f"{'DAVIS-17 val clip ' + real['name'] if real is not None else 'DAVIS-17-val-shaped'} {H}x{W} (padded {pad_hw[0]}x{pad_hw[1]}) {'single' if K_OBJ == 1 else K_OBJ}-object "
                                    f"STCN propagate: fresh engine, interact(mask,0), T={T} frames/video, "
                                    f"mem_freq={a.mem_freq}, top_k=50; one video per step per GPU",
                        "frames_per_step": T - 1, "videos_per_gpu": a.steps, "sharding": f"videos x{world}", "streams_per_gpu": S,
                        "key_lookahead": int(os.environ["STCN_LOOKAHEAD"]),
                        "clips": f"{S * per_lane} distinct synthetic clips (one per pooled engine)",
-                       "weights": "synthetic recipe seed 0 (no checkpoints offline)"},
+                       "weights": "model_weights/mivos/stcn.pth + fusion.pth" if real is not None else "synthetic recipe seed 0 (no checkpoints offline)"},
             "ms_per_frame": 1e3 * dt_all / (frames_all / world),
             "jf_rows_rank_J_F_JF": rows.round(4).tolist(),
             "concurrent_videos_bit_identical": bool(lanes_identical),
@@ -380,9 +538,17 @@ def main():
             out["timed_region_tflops"] = out["algorithmic_gflop_per_frame"] * 1e-3 * frames / dt_r1
         else:
             out["roofline"] = None
+        if cfg3 is not None:
+            out["config3"] = cfg3
+        if mr_roof is not None:
+            out["roofline_memread"] = mr_roof
         if world == 1 and a.cpu_frames > 1:
             out["cpu_baseline"], sample = cpu_baseline(psd, fsd, H, W, a.cpu_frames, a.mem_freq)
             out["parity_vs_cpu_oracle"] = parity_vs_oracle(prop, fuse, sample, a.mem_freq)
+        else:
+            out["cpu_baseline"] = None
+            out["cpu_baseline_note"] = ("the CPU oracle is timed on rank 0 at N=1 only (task contract); see the N=1 line" if world > 1
+                                        else "skipped (--cpu-frames 0)")
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -156,7 +156,38 @@ def fusion_case(tag, H, W, fus, fsd, out):
     return {"fusion": dmax(ref, o)}
 
 
-def seq_case(tag, H, W, k, T, mem_freq, script, net, fus, psd, fsd, out):
+def self_noise(tag, H, W, k, T, mem_freq, script, net, fus, **_):
+    """Noise floor of the REFERENCE ITSELF: the same sequence run with 1 and with 8 intra-op threads (different fp32
+    summation orders inside the CPU kernels).  Returns per round: worst per-object (1 - IoU) between the two runs, max and
+    p99.9 |prob| difference.  Tests bound HIP-vs-reference mask differences by max(1e-3, this floor)."""
+    img = synth.synthetic_clip(T, H, W)
+    msk = synth.synthetic_mask(T, H, W, k)
+    runs = []
+    for nt in (1, 8):
+        torch.set_num_threads(nt)
+        ref = RefCore(net, fus, img, k, mem_freq=mem_freq, device="cpu")
+        res = []
+        for mf, idx in script:
+            m = msk[:, mf]
+            if k > 1:
+                m = torch.cat([1 - m.sum(0, keepdim=True).clamp(0, 1), m], 0)
+            rm = ref.interact(m.clone(), idx, scribble=k > 1)
+            res.append((rm.copy(), ref.prob.clone()))
+        runs.append(res)
+    torch.set_num_threads(8)
+    rows = []
+    for (m1, p1), (m8, p8) in zip(*runs):
+        worst = 0.0
+        for o in range(1, k + 1):
+            a, b = m1 == o, m8 == o
+            u = (a | b).sum()
+            worst = max(worst, 0.0 if u == 0 else 1.0 - float((a & b).sum() / u))
+        d = (p1 - p8).abs()
+        rows.append([worst, float(d.max()), float(torch.quantile(d.flatten()[::7], 0.999)), float((m1 != m8).sum())])
+    return np.array(rows, np.float64)
+
+
+def seq_case(tag, H, W, k, T, mem_freq, script, net, fus, psd, fsd, out, prob_stride=2):
     """script: list of (frame_idx_for_mask, idx) interactions."""
     img = synth.synthetic_clip(T, H, W)
     msk = synth.synthetic_mask(T, H, W, k)
@@ -171,7 +202,7 @@ def seq_case(tag, H, W, k, T, mem_freq, script, net, fus, psd, fsd, out):
         rm = ref.interact(m.clone(), idx, scribble=scribble)
         om = orc.interact(m.clone(), idx, scribble=scribble)
         out[f"{tag}.r{r}.masks"] = np.packbits(rm.astype(bool), axis=None) if k == 1 else rm
-        out[f"{tag}.r{r}.prob_h"] = ref.prob[:, :, 0, ::2, ::2].numpy().astype(np.float16)
+        out[f"{tag}.r{r}.prob_h"] = ref.prob[:, :, 0, ::prob_stride, ::prob_stride].numpy().astype(np.float16)
         put(out, f"{tag}.r{r}.prob", ref.prob, stride=97)
         rep[f"r{r}.prob"] = dmax(ref.prob, orc.prob)
         rep[f"r{r}.mask_mismatch"] = int((rm != om).sum())
@@ -179,6 +210,8 @@ def seq_case(tag, H, W, k, T, mem_freq, script, net, fus, psd, fsd, out):
                                      for t in orc.trace])
     out[f"{tag}.shape"] = np.array([T, H, W, k, mem_freq])
     out[f"{tag}.script"] = np.array(script)
+    if prob_stride != 2:
+        out[f"{tag}.prob_stride"] = np.array(prob_stride)
     return rep
 
 
@@ -188,6 +221,11 @@ SEQ_CASES = {
     "seqC": dict(H=128, W=160, k=3, T=8, mem_freq=2, script=[(0, 0), (5, 5)]),
     # config-3-shaped: 5 objects, every frame enters the bank, ragged size (pads 4/4 and 3/3)
     "seqD": dict(H=120, W=170, k=5, T=7, mem_freq=1, script=[(0, 0), (4, 4)]),
+}
+# BASELINE resolution end to end from the reference: 6 frames 480x854 (padded to 864), interact(0) then interact(4) with
+# fusion on frames 1..3; packed masks + every 4th prob sample as fp16 (< 1 MB).  ~1.6 s per frame and network pass here.
+FULL_CASES = {
+    "seq480": dict(H=480, W=854, k=1, T=6, mem_freq=2, script=[(0, 0), (4, 4)], prob_stride=4),
 }
 STAGE_CASES = {
     "stA": dict(H=128, W=160, k=1),
@@ -200,9 +238,21 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     net, fus, psd, fsd = load_reference()
     only = [a.split("=")[1] for a in sys.argv if a.startswith("--only=")]      # e.g. --only=seqD: just that fixture
+    if "--selfnoise" in sys.argv:     # reference-vs-reference (1 vs 8 threads) floors of every sequence fixture
+        out = {}
+        for tag, c in {**SEQ_CASES, **FULL_CASES}.items():
+            out[tag] = self_noise(tag, net=net, fus=fus, **c)
+            print("selfnoise", tag, out[tag].tolist())
+        np.savez_compressed(os.path.join(GOLD, "selfnoise.npz"), **out)
+        return
     if only:
         for tag in only:
             out = {}
+            if tag in FULL_CASES:
+                rep = seq_case(tag, net=net, fus=fus, psd=psd, fsd=fsd, out=out, **FULL_CASES[tag])
+                np.savez_compressed(os.path.join(GOLD, f"{tag}.npz"), **out)
+                print(tag, rep)
+                continue
             if tag in STAGE_CASES:
                 c = STAGE_CASES[tag]
                 rep = stage_case(tag, c["H"], c["W"], c["k"], net, psd, out)

@@ -143,16 +143,22 @@ def affinity_logits(mk, qk):
     return (2.0 * (mk @ qk.t()) - a - c) / math.sqrt(mk.shape[1])
 
 
-def memory_read(mk, mv, qk):
+def memory_read(mk, mv, qk, return_gap=False):
     """Sparse top-50 read.  mk [N,64], mv [k,N,512], qk [Q,64].
-    Returns (idx [Q,50] descending score, w [Q,50] softmax over the 50, readout [k,Q,512])."""
+    Returns (idx [Q,50] descending score, w [Q,50] softmax over the 50, readout [k,Q,512]) and, with return_gap, the
+    per-query gap between the 50th and the 51st score (inf when N == 50): the membership of the top-50 set - and with it
+    the read-out - is ill-conditioned exactly where this gap is at the level of fp32 rounding of the scores (~1e-5 for
+    |S| ~ 100), whatever the implementation (tests use it to tell such queries from real errors)."""
     S = affinity_logits(mk, qk)
-    vals, idx = torch.topk(S, TOP_K, dim=0)              # [50,Q], sorted descending
+    kk = min(TOP_K + 1, S.shape[0]) if return_gap else TOP_K
+    vals, idx = torch.topk(S, kk, dim=0)                 # sorted descending
+    gap = (vals[TOP_K - 1] - vals[TOP_K]) if kk > TOP_K else torch.full((S.shape[1],), float("inf"))
+    vals, idx = vals[:TOP_K], idx[:TOP_K]
     e = torch.exp(vals - vals[0:1])
     w = (e / e.sum(0, keepdim=True)).t().contiguous()    # [Q,50]
     idx = idx.t().contiguous()
     out = torch.einsum("qj,kqjc->kqc", w, mv[:, idx])    # gather 50 rows per query
-    return idx, w, out
+    return (idx, w, out, gap) if return_gap else (idx, w, out)
 
 
 def decode(fw, readout, f16_thin, f8, f4):
@@ -234,6 +240,7 @@ class OracleCore:
         self.interacted = set()
         self.certain_k, self.certain_v = [], []     # one slot per interaction, never evicted
         self.trace = []                              # bank sizes per pass (for tests)
+        self.tie_log = []                            # per memory read: (round, frame, gap [Q]) in processing order
         self.stage_seconds = {}
 
     # -- helpers --------------------------------------------------------------------------
@@ -252,7 +259,8 @@ class OracleCore:
         k16, f16_thin, _f16, f8, f4 = self._keys(ti)
         mk = torch.cat(bank_k, 0)
         mv = torch.cat(bank_v, 1)
-        _, _, ro = memory_read(mk, mv, self._rows(k16)[0])
+        _, _, ro, gap = memory_read(mk, mv, self._rows(k16)[0], return_gap=True)
+        self.tie_log.append((len(self.interacted), ti, gap))     # (interaction round, frame, 50th-51st score gap per query)
         ro = ro.transpose(1, 2).reshape(self.k, 512, self.kh, self.kw)
         prob, _ = decode(self.fw, ro, f16_thin, f8, f4)
         return aggregate(prob)
