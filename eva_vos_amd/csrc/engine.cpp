@@ -301,6 +301,15 @@ void Work::release() {
 }
 
 // ---------------------------------------------------------------------------------------------- stages
+// a kernel launch that fails (bad configuration, LDS opt-in missing on this device ...) is reported where it happens, with
+// the launch class that failed - not as an anonymous error at the end of the interaction
+int launch_status(const char *what) {
+    const hipError_t er = hipGetLastError();
+    if (er == hipSuccess) return STCN_OK;
+    set_error("launch of '%s' failed: %s", what, hipGetErrorString(er));
+    return STCN_E_HIP;
+}
+
 int run_conv(const Model &m, Work &w, hipStream_t s, const char *name, const float *x0, int c0, long bs0,
              const float *x1, int c1, long bs1, int B, int H, int W, int stride, float *y, long y_bs,
              const float *res, long res_bs, int relu_in, int relu_out, int force_splitk) {
@@ -349,7 +358,7 @@ int run_conv(const Model &m, Work &w, hipStream_t s, const char *name, const flo
         if (p.splitk > 1 || p.rem_split > 1) er = w.prof->attach(STCN_K_CONV_REDUCE);
     }
     conv_launch(p, s, eg, er);
-    return STCN_OK;
+    return launch_status(name);
 }
 
 #define RC(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
@@ -610,16 +619,35 @@ static SlotPtrs slot_ptrs(const stcn_engine *e, int slot) {
     return p;
 }
 
+// frees bank buffers replaced by bank_reserve once the copies out of them have finished (never blocks)
+static void bank_collect_retired(stcn_engine *e, bool wait) {
+    if (e->retired.empty()) return;
+    if (wait) (void)hipEventSynchronize(e->retire_ev);
+    else if (hipEventQuery(e->retire_ev) != hipSuccess) return;
+    for (void *p : e->retired) (void)hipFree(p);
+    e->retired.clear();
+}
+
+// Grows the memory bank to `slots` frames.  Enqueue-only: the certain slots are copied on the engine stream and the old
+// buffers are retired (freed once an event behind the copies has fired), so a long annotation session (config 5: up to 60
+// interactions = 60 certain slots) never stalls the host in the middle of an interaction.
 static int bank_reserve(stcn_engine *e, int slots) {
     if (slots <= e->bank_cap) return STCN_OK;
     const Dims &d = e->d;
     int cap = e->bank_cap ? e->bank_cap : 8;
     while (cap < slots) cap *= 2;
-    float *nk, *nq, *nv;
+    float *nk = nullptr, *nq = nullptr, *nv = nullptr;
     const size_t rows = (size_t)cap * d.hw16;
-    HIPCHK(hipMalloc((void **)&nk, rows * 64 * 4));
-    HIPCHK(hipMalloc((void **)&nq, (rows + 64) * 4));      // +64: the read kernels fetch msq in 64-row steps
-    HIPCHK(hipMalloc((void **)&nv, (size_t)e->k * rows * 512 * 4));
+    hipError_t er = hipMalloc((void **)&nk, rows * 64 * 4);
+    if (er == hipSuccess) er = hipMalloc((void **)&nq, (rows + 64) * 4);      // +64: the read kernels fetch msq in 64-row steps
+    if (er == hipSuccess) er = hipMalloc((void **)&nv, (size_t)e->k * rows * 512 * 4);
+    if (er != hipSuccess) {
+        if (nk) (void)hipFree(nk);
+        if (nq) (void)hipFree(nq);
+        if (nv) (void)hipFree(nv);
+        set_error("bank_reserve: %d slots (%zu MB) -> %s", cap, ((size_t)e->k * rows * 512 * 4 + rows * 65 * 4) >> 20, hipGetErrorString(er));
+        return STCN_E_HIP;
+    }
     if (e->n_certain > 0) {
         const size_t crow = (size_t)e->n_certain * d.hw16, orow = (size_t)e->bank_cap * d.hw16;
         HIPCHK(hipMemcpyAsync(nk, e->bank_k, crow * 64 * 4, hipMemcpyDeviceToDevice, e->stream));
@@ -628,8 +656,12 @@ static int bank_reserve(stcn_engine *e, int slots) {
             HIPCHK(hipMemcpyAsync(nv + o * rows * 512, e->bank_v + o * orow * 512, crow * 512 * 4,
                                   hipMemcpyDeviceToDevice, e->stream));
     }
-    HIPCHK(hipStreamSynchronize(e->stream));
-    if (e->bank_k) { (void)hipFree(e->bank_k); (void)hipFree(e->bank_msq); (void)hipFree(e->bank_v); }
+    if (e->bank_k) {
+        bank_collect_retired(e, true);                  // an older generation still pending: wait for it (rare)
+        if (!e->retire_ev) HIPCHK(hipEventCreateWithFlags(&e->retire_ev, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(e->retire_ev, e->stream));
+        e->retired = {e->bank_k, e->bank_msq, e->bank_v};
+    }
     e->bank_k = nk; e->bank_msq = nq; e->bank_v = nv; e->bank_cap = cap;
     return STCN_OK;
 }
@@ -735,6 +767,8 @@ int stcn_engine_destroy(stcn_engine *e) {
     e->work_side.release();
     for (void *p : e->allocs) (void)hipFree(p);
     if (e->bank_k) { (void)hipFree(e->bank_k); (void)hipFree(e->bank_msq); (void)hipFree(e->bank_v); }
+    bank_collect_retired(e, true);
+    if (e->retire_ev) (void)hipEventDestroy(e->retire_ev);
     e->work.release();
     delete e;
     return STCN_OK;
@@ -945,6 +979,7 @@ static int do_pass(stcn_engine *e, int idx, bool forward) {
             e->prof.bytes[STCN_K_MEMREAD] += memread_bytes(N, d.hw16, k);
             memory_read_launch(e->bank_k, e->bank_msq, f.k16, N, d.hw16, e->bank_v, (long)e->bank_cap * d.hw16 * 512, k, readout,
                                (long)d.hw16 * 512, nullptr, nullptr, MemReadScratch{w.cand_v, w.cand_i, w.cand_n, w.gmax, w.tau}, e->stream);
+            return launch_status("memory read");
         };
         // agg of the frame at sweep position g lives at w.agg + pos(g) * agg_fs
         auto pos = [&](int g) { return batched ? (ti + g * step) - t_lo : 0; };
@@ -961,6 +996,7 @@ static int do_pass(stcn_engine *e, int idx, bool forward) {
                                    w.readout, (long)G * d.hw16 * 512, nullptr, nullptr, MemReadScratch{w.cand_v, w.cand_i, w.cand_n, w.gmax, w.tau},
                                    e->stream);
             }
+            RC(launch_status("memory read (decode group)"));
             RC(decode(*e->model, w, e->stream, w.readout, f0.f16_thin, f0.s8, f0.s4, w.agg, d.npix, f0.dthin, f0.cthin, G,
                       (long)e->slot_floats));
         }
@@ -970,7 +1006,7 @@ static int do_pass(stcn_engine *e, int idx, bool forward) {
             const SlotPtrs &f = kf[g];
             float *agg = w.agg + (size_t)pos(g) * agg_fs;
             if (!batched) {
-                read(f, w.readout);
+                RC(read(f, w.readout));
                 dbg_sum(e, "k16", t, f.k16, (size_t)d.hw16 * 64);
                 dbg_sum(e, "readout", t, w.readout, (size_t)k * d.hw16 * 512);
                 RC(decode(*e->model, w, e->stream, w.readout, f.f16_thin, f.s8, f.s4, agg, d.npix, f.dthin, f.cthin));
@@ -992,6 +1028,7 @@ static int do_pass(stcn_engine *e, int idx, bool forward) {
                     attention_read_launch(e->bank_k + (size_t)cs * d.hw16 * 64, e->bank_msq + (size_t)cs * d.hw16, f.k16, e->pos,
                                           e->neg, k + 1, d.h16, d.w16, w.pooled, w.amap, w.attn, AttnScratch{w.gmax, w.tau, w.cand_v}, e->stream);
                 }
+                RC(launch_status("attention read"));
                 for (int o = 1; o <= k; ++o)
                     RC(fusion_logit(*e->model, w, e->stream, e->images4 + (size_t)t * d.npix * 4, dst + (size_t)o * prs,
                                     agg + (size_t)o * d.npix, w.attn + (size_t)o * 2 * d.npix, nc, nr,
@@ -1023,6 +1060,7 @@ int stcn_interact(stcn_engine *e, const float *mask_dev, int mask_channels, int 
         return STCN_E_INVALID;
     }
     HIPCHK(hipSetDevice(e->model->device));
+    bank_collect_retired(e, false);
     const Dims &d = e->d;
     e->stats = stcn_stats{};
     e->prof.reset();

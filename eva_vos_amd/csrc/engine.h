@@ -102,6 +102,7 @@ struct Work {
 
 // ---- stages (enqueue only) -----------------------------------------------------------------
 struct KeyOut { float *k16, *msq, *f16_thin, *f16, *s8, *s4, *f8_copy, *f4_copy, *dthin = nullptr, *cthin = nullptr; };
+int launch_status(const char *what);     // STCN_OK, or STCN_E_HIP with the failing launch class in the error string
 int run_conv(const Model &m, Work &w, hipStream_t s, const char *name, const float *x0, int c0, long bs0,
              const float *x1, int c1, long bs1, int B, int H, int W, int stride, float *y, long y_bs,
              const float *res, long res_bs, int relu_in, int relu_out, int force_splitk = 0);
@@ -144,6 +145,8 @@ struct stcn_engine {
     // memory bank: rows = slots * hw16
     int bank_cap = 0, n_certain = 0;
     float *bank_k = nullptr, *bank_msq = nullptr, *bank_v = nullptr;
+    std::vector<void *> retired;       // bank buffers replaced by a larger generation, freed once retire_ev has fired
+    hipEvent_t retire_ev = nullptr;
     std::set<int> interacted;
     float *mask_pad = nullptr, *pos = nullptr, *neg = nullptr;   // [k+1][npix] each
     stcn::Work work;

@@ -229,6 +229,27 @@ def save_state_masks(gen: torch.Tensor, out_dir: str, pool=None):
     return pool.submit(write)
 
 
+def save_rgb_frames(rgb: torch.Tensor, out_dir: str, pool=None):
+    """RGBFrames/224/<video>/%05d.png like util/fq_dataset.py:26-47 (``save_frames``): each normalised frame is resized to
+    224x224 (bicubic, antialias), min-max normalised PER FRAME (``im_normalize``) and written as 8-bit RGB - the inputs of
+    the reference's QNet training set.  rgb: [T,3,H,W] float (ImageNet-normalised, host or device); the resize runs where
+    the tensor lives, the PNG encoding on `pool` threads when given."""
+    small = torch.nn.functional.interpolate(rgb.float(), size=(224, 224), mode="bicubic", align_corners=False, antialias=True)
+    lo = small.amin((1, 2, 3), keepdim=True)
+    hi = small.amax((1, 2, 3), keepdim=True)
+    frames = ((small - lo) / (hi - lo).clamp_min(1e-8) * 255).to(torch.uint8).permute(0, 2, 3, 1).cpu().numpy()
+
+    def write():
+        os.makedirs(out_dir, exist_ok=True)
+        for t, m in enumerate(frames):
+            Image.fromarray(m).save(os.path.join(out_dir, f"{t:05d}.png"))
+
+    if pool is None:
+        write()
+        return None
+    return pool.submit(write)
+
+
 def run(root: str, imset: str, out: str, prop_net, fuse_net, rounds: int = 8, save_masks: bool = True,
         device: str = "cuda", lanes: int = 2):
     """Process this rank's share of the samples (`lanes` videos in flight); returns the gathered rows on every rank
@@ -246,8 +267,17 @@ def run(root: str, imset: str, out: str, prop_net, fuse_net, rounds: int = 8, sa
     writers = ThreadPoolExecutor(4) if save_masks else None
     pending = []
 
+    saved_rgb = set()
+    rgb_lock = __import__("threading").Lock()
+
     def work(i, sample):
         rows = []
+        if save_masks:                                     # once per video (generate_fq_dataset.py:77-80)
+            with rgb_lock:
+                first = sample["video"] not in saved_rgb
+                saved_rgb.add(sample["video"])
+            if first:
+                pending.append(save_rgb_frames(sample["rgb"][0], os.path.join(out, "RGBFrames", "224", sample["video"]), writers))
         proc = InferenceCore(prop_net, fuse_net, sample["rgb"], 1)
         states, gens = oracle_rounds(proc, sample, rounds)
         sid = 1
@@ -272,13 +302,14 @@ def run(root: str, imset: str, out: str, prop_net, fuse_net, rounds: int = 8, sa
     if rank == 0:
         os.makedirs(out, exist_ok=True)
         order = np.lexsort((allrows[:, 1], allrows[:, 0]))
-        with open(os.path.join(out, "res_fq.csv"), "w", newline="") as f:
+        # res_<imset>.csv, columns as generate_fq_dataset.py:48-52,85-86 (the ious cell holds the per-frame list)
+        imset_str = os.path.splitext(os.path.basename(imset))[0]
+        with open(os.path.join(out, f"res_{imset_str}.csv"), "w", newline="") as f:
             wr = csv.writer(f)
             wr.writerow(["state_name", "ious", "selected_frame"])
             for row in allrows[order]:
                 n = int(row[3])
-                wr.writerow([f"{ds.name(int(row[0]))}_round_{int(row[1])}", [round(float(v), 6) for v in row[4:4 + n]],
-                             int(row[2])])
+                wr.writerow([f"{ds.name(int(row[0]))}_round_{int(row[1])}", [float(v) for v in row[4:4 + n]], int(row[2])])
     return allrows
 
 
@@ -310,7 +341,7 @@ def main():
         fuse.load_state_dict(torch.load(a.fusion_weights, map_location="cpu"))
     rows = run(a.root, a.imset, a.out, prop.eval(), fuse.eval(), a.rounds, lanes=a.lanes)
     if not dist.is_initialized() or dist.get_rank() == 0:
-        print(f"{len(rows)} states -> {os.path.join(a.out, 'res_fq.csv')}")
+        print(f"{len(rows)} states -> {os.path.join(a.out, 'res_' + os.path.splitext(os.path.basename(a.imset))[0] + '.csv')}")
     if dist.is_initialized():
         dist.destroy_process_group()
 

@@ -53,13 +53,31 @@ class _Model:
 _MODEL_LOCK = threading.Lock()
 
 
+def _fingerprint(module) -> tuple:
+    """(storage address, in-place version) of every tensor of the state_dict: changes when a checkpoint is loaded into the
+    module (load_state_dict copies in place and bumps the versions) or a parameter is replaced."""
+    if module is None:
+        return ()
+    return tuple((v.data_ptr(), v._version) for v in module.state_dict(keep_vars=True).values())
+
+
 def _model_for(prop_net, fuse_net, device_index: int) -> _Model:
+    """The engine works on a BN-folded, repacked SNAPSHOT of the weights.  The reference reads the live parameters, so the
+    snapshot is keyed on a fingerprint of both modules' tensors: loading another checkpoint into the same module objects
+    (one script evaluating several checkpoints) yields a fresh model; the stale one dies with its last engine."""
     with _MODEL_LOCK:                       # engines may be created from several host threads (one per video)
         per_net = _MODEL_CACHE.setdefault(prop_net, {})
-        key = (id(fuse_net), device_index)
-        if key not in per_net:
-            per_net[key] = _Model(prop_net, fuse_net, device_index)
-        return per_net[key]
+        key = (device_index, _fingerprint(prop_net), _fingerprint(fuse_net))
+        hit = per_net.get(key)
+        # the fuse_net is held weakly and compared by identity: a new module that happens to reuse a freed one's id /
+        # storage addresses must not alias its packed weights
+        if hit is not None and (hit[1]() if hit[1] is not None else None) is fuse_net:
+            return hit[0]
+        for k in [k for k in per_net if k[0] == device_index]:      # snapshots of older weights of this module: drop
+            del per_net[k]
+        model = _Model(prop_net, fuse_net, device_index)
+        per_net[key] = (model, weakref.ref(fuse_net) if fuse_net is not None else None)
+        return model
 
 
 def _pad16(n: int):
@@ -111,12 +129,16 @@ class InferenceCore:
         that evaluate on the device (``processor.masks`` / ``processor.prob``, e.g. eva_vos_amd.eval_driver) save the
         27 MB transfer + host sync per annotation round."""
         idx = int(idx)
-        mask = mask.detach().to(self.device, torch.float32).contiguous()
-        if mask.dim() != 4 or mask.shape[1] != 1 or tuple(mask.shape[-2:]) != (self.h, self.w):
-            raise RuntimeError(f"mask must be [C,1,{self.h},{self.w}], got {tuple(mask.shape)}")
         with torch.cuda.device(self.device):
-            _lib.check(_lib.lib().stcn_interact(self._engine, mask.data_ptr(), int(mask.shape[0]), idx,
-                                                1 if scribble else 0), "stcn_interact")
+            mask = mask.detach().to(self.device, torch.float32).contiguous()
+            if mask.dim() != 4 or mask.shape[1] != 1 or tuple(mask.shape[-2:]) != (self.h, self.w):
+                raise RuntimeError(f"mask must be [C,1,{self.h},{self.w}], got {tuple(mask.shape)}")
+            cur = self._join_engine_stream(mask)
+            try:
+                _lib.check(_lib.lib().stcn_interact(self._engine, mask.data_ptr(), int(mask.shape[0]), idx,
+                                                    1 if scribble else 0), "stcn_interact")
+            finally:
+                self._leave_engine_stream(cur)
             self.interacted.add(idx)
             if not download:
                 return None
@@ -125,11 +147,31 @@ class InferenceCore:
             self.np_masks = out.cpu().numpy().astype(np.uint8)     # D2H sync, as the reference's .cpu()
         return self.np_masks
 
+    # The engine enqueues on the HIP stream that was current when the core was constructed.  Normal PyTorch stream
+    # semantics are kept for callers that use the core under ANOTHER current stream: the engine stream first waits for the
+    # caller's stream (the mask was produced there), and the caller's stream then waits for the engine, so whatever the
+    # caller enqueues next on prob / masks is ordered behind the propagation.
+    def _join_engine_stream(self, *tensors):
+        cur = torch.cuda.current_stream()
+        if cur != self._stream:
+            self._stream.wait_stream(cur)
+            for t in tensors:
+                t.record_stream(self._stream)          # the caching allocator must not recycle it under the engine
+        return cur
+
+    def _leave_engine_stream(self, cur):
+        if cur != self._stream:
+            cur.wait_stream(self._stream)
+
     def reset(self):
         """Forget all interactions / cached features (same clip): equivalent to constructing a new
         InferenceCore on the same images, without re-allocating device memory."""
         with torch.cuda.device(self.device):
-            _lib.check(_lib.lib().stcn_engine_reset(self._engine), "stcn_engine_reset")
+            cur = self._join_engine_stream()
+            try:
+                _lib.check(_lib.lib().stcn_engine_reset(self._engine), "stcn_engine_reset")
+            finally:
+                self._leave_engine_stream(cur)
         self.interacted = set()
         self.np_masks = np.zeros((self.t, self.h, self.w), dtype=np.uint8)
 
@@ -171,6 +213,7 @@ class InferenceCore:
                 continue
             new.__dict__[k] = v                                   # nets, model handle, images: shared (read-only)
         with torch.cuda.device(self.device):
+            self._leave_engine_stream(torch.cuda.current_stream())     # the clones below read what the engine stream wrote
             torch.cuda.current_stream().synchronize()
             new.prob, new.masks = self.prob.clone(), self.masks.clone()
             new.np_masks, new.interacted = self.np_masks.copy(), set(self.interacted)

@@ -157,13 +157,14 @@ def fusion_case(tag, H, W, fus, fsd, out):
 
 
 def self_noise(tag, H, W, k, T, mem_freq, script, net, fus, **_):
-    """Noise floor of the REFERENCE ITSELF: the same sequence run with 1 and with 8 intra-op threads (different fp32
-    summation orders inside the CPU kernels).  Returns per round: worst per-object (1 - IoU) between the two runs, max and
-    p99.9 |prob| difference.  Tests bound HIP-vs-reference mask differences by max(1e-3, this floor)."""
+    """Noise floor of the REFERENCE ITSELF: the same sequence run with 1, 2, 4 and 8 intra-op threads (different fp32
+    summation orders inside the CPU kernels) - four equally valid executions of the reference.  Returns per round the
+    WORST over the six pairs of: per-object (1 - IoU), max and p99.9 |prob| difference, differing mask pixels.  Tests
+    bound an implementation's mask difference from the golden by max(1e-3, this envelope)."""
     img = synth.synthetic_clip(T, H, W)
     msk = synth.synthetic_mask(T, H, W, k)
     runs = []
-    for nt in (1, 8):
+    for nt in (1, 2, 4, 8):
         torch.set_num_threads(nt)
         ref = RefCore(net, fus, img, k, mem_freq=mem_freq, device="cpu")
         res = []
@@ -175,16 +176,18 @@ def self_noise(tag, H, W, k, T, mem_freq, script, net, fus, **_):
             res.append((rm.copy(), ref.prob.clone()))
         runs.append(res)
     torch.set_num_threads(8)
-    rows = []
-    for (m1, p1), (m8, p8) in zip(*runs):
-        worst = 0.0
-        for o in range(1, k + 1):
-            a, b = m1 == o, m8 == o
-            u = (a | b).sum()
-            worst = max(worst, 0.0 if u == 0 else 1.0 - float((a & b).sum() / u))
-        d = (p1 - p8).abs()
-        rows.append([worst, float(d.max()), float(torch.quantile(d.flatten()[::7], 0.999)), float((m1 != m8).sum())])
-    return np.array(rows, np.float64)
+    rows = np.zeros((len(script), 4), np.float64)
+    for i in range(len(runs)):
+        for j in range(i + 1, len(runs)):
+            for r, ((m1, p1), (m8, p8)) in enumerate(zip(runs[i], runs[j])):
+                worst = 0.0
+                for o in range(1, k + 1):
+                    a, b = m1 == o, m8 == o
+                    u = (a | b).sum()
+                    worst = max(worst, 0.0 if u == 0 else 1.0 - float((a & b).sum() / u))
+                d = (p1 - p8).abs()
+                rows[r] = np.maximum(rows[r], [worst, float(d.max()), float(torch.quantile(d.flatten()[::7], 0.999)), float((m1 != m8).sum())])
+    return rows
 
 
 def seq_case(tag, H, W, k, T, mem_freq, script, net, fus, psd, fsd, out, prob_stride=2):

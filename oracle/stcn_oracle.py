@@ -260,7 +260,7 @@ class OracleCore:
         mk = torch.cat(bank_k, 0)
         mv = torch.cat(bank_v, 1)
         _, _, ro, gap = memory_read(mk, mv, self._rows(k16)[0], return_gap=True)
-        self.tie_log.append((len(self.interacted), ti, gap))     # (interaction round, frame, 50th-51st score gap per query)
+        self.tie_log.append((len(self.certain_k), ti, gap))      # (interaction round, frame, 50th-51st score gap per query)
         ro = ro.transpose(1, 2).reshape(self.k, 512, self.kh, self.kw)
         prob, _ = decode(self.fw, ro, f16_thin, f8, f4)
         return aggregate(prob)

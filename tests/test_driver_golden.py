@@ -1,0 +1,49 @@
+"""CPU: the callers either side of the path against fixtures captured from the reference (oracle/gen_golden_driver.py):
+clip loader vs datasets/annotation_dataset.py:80-132, FQ-dataset writer vs util/fq_dataset.py:26-91."""
+import os
+
+import numpy as np
+import torch
+from PIL import Image
+
+from conftest import load_golden
+from eva_vos_amd import fq_driver
+
+TREE = {"vidA": (4, 48, 64, 2), "vidB": (3, 60, 80, 1)}          # the tree oracle/gen_golden_driver.py captured
+
+
+def test_clip_loader_equals_the_reference_dataset(tmp_path):
+    g = load_golden("driver")
+    imset = fq_driver.make_synthetic_tree(str(tmp_path), TREE)
+    ds = fq_driver.ClipDataset(str(tmp_path), imset)
+    assert [ds.name(i) for i in range(len(ds))] == g["names"].tolist()       # one sample per (video, object), same order
+    for i in range(len(ds)):
+        smp = ds[i]
+        rgb, gt = smp["rgb"][0], smp["gt"]
+        assert list(rgb.shape) == g[f"s{i}.rgb_shape"].tolist() and list(gt.shape) == g[f"s{i}.gt_shape"].tolist()
+        assert smp["num_frames"] == int(g[f"s{i}.num_frames"])
+        # ToTensor + ImageNet normalisation: same float32 values as the reference pipeline (1 ulp of slack)
+        assert np.abs(rgb.reshape(-1)[::101].numpy() - g[f"s{i}.rgb_sample"]).max() < 5e-7
+        assert abs(float(rgb.double().abs().sum()) - g[f"s{i}.rgb_sum"][1]) < 1e-3
+        want = np.unpackbits(g[f"s{i}.gt"])[: gt.numel()].reshape(gt.shape).astype(bool)
+        assert np.array_equal(gt.numpy() > 0.5, want)                        # object of interest, no background channel
+
+
+def test_fq_writer_equals_the_reference_writer(tmp_path):
+    g = load_golden("driver")
+    n, T, H, W = [int(v) for v in g["writer.gen_shape"]]
+    gens = np.unpackbits(g["writer.gen"])[: n * T * H * W].reshape(n, T, H, W)
+    for sid in (1, 2):                                                       # 224x224 nearest-resized mask states
+        d = str(tmp_path / f"state{sid}")
+        fq_driver.save_state_masks(torch.from_numpy(gens[sid - 1]), d)
+        got = np.stack([np.array(Image.open(os.path.join(d, f"{t:05d}.png"))) for t in range(T)])
+        assert got.dtype == np.uint8 and np.array_equal(got, g[f"writer.masks{sid}"])
+    assert g["writer.state_names"].tolist() == ["vidA__1_round_1", "vidA__1_round_2"] and int(g["writer.next_id"]) == 3
+    # RGB frames: bicubic-antialias 224x224 + per-frame min-max normalisation
+    imset = fq_driver.make_synthetic_tree(str(tmp_path / "db"), TREE)
+    rgb = fq_driver.ClipDataset(str(tmp_path / "db"), imset)[0]["rgb"][0]
+    d = str(tmp_path / "rgb")
+    fq_driver.save_rgb_frames(rgb, d)
+    got = np.stack([np.array(Image.open(os.path.join(d, f"{t:05d}.png"))) for t in range(T)])
+    assert got.shape == g["writer.rgb224"].shape
+    assert np.abs(got.astype(int) - g["writer.rgb224"].astype(int)).max() <= 1        # float rounding before the uint8 cast

@@ -87,31 +87,94 @@ def run_sequence(core_factory, tag, g):
     return outs
 
 
-def check_sequence_against_golden(outs, tag, g, prob_atol, min_iou=1 - 1e-3):
+NEAR_TIE = 3e-5      # 50th-51st score gap below which the top-50 membership of a query is at the mercy of fp32 rounding
+                     # (scores |S| ~ 100: one ulp is 7.6e-6, a 64-term dot product carries ~1e-5 of rounding noise; two
+                     # implementations then legitimately select different rows)
+
+
+def tie_summary(orc):
+    """From the oracle's log of 50th/51st score gaps (one entry per memory read, in processing order): per interaction
+    round, the frames propagated BEFORE the first near-tie read of the run ("clean": every implementation selects the same
+    50 rows for every query so far, so results may differ by fp32 rounding only), and the near-tie / total query counts."""
+    rounds, dirty = {}, False
+    for rnd, frame, gap in orc.tie_log:
+        r = rounds.setdefault(rnd - 1, dict(clean=set(), near=0, queries=0))
+        near = int((gap < NEAR_TIE).sum())
+        r["near"] += near
+        r["queries"] += int(gap.numel())
+        dirty = dirty or near > 0
+        if not dirty:
+            r["clean"].add(frame)
+    return rounds
+
+
+def check_sequence_against_golden(outs, tag, g, prob_atol, min_iou=1 - 1e-3, ties=None, clean_atol=6e-4, who="oracle"):
+    """outs: [(masks, prob)] per round.  Three statements, each of which can fail:
+    (1) masks: IoU >= 1 - 1e-3 (north_star) - for k > 1 per object and against max(1e-3, 3 x the reference's own worst
+        difference between 1 / 2 / 4 / 8 threads on this very sequence, tests/golden/selfnoise.npz: 128x160 objects are ~2000
+        pixels, 1e-3 of IoU is two pixels per frame, and the reference moves 29-39 pixels against itself);
+    (2) with `ties` (tie_summary of an oracle run on the same inputs): on frames propagated before the first near-tie of the
+        50th/51st score the probabilities agree EVERYWHERE (max, not a quantile) to clean_atol = fp16 quantisation of the
+        golden (2.5e-4) + fp32 noise, and the near-tie queries are few;
+    (3) on the remaining frames a swapped member at a near-tie moves the probabilities of that query's neighbourhood by
+        ~1e-2 (demonstrated at stage level by tests/test_gpu_kernels.py::test_near_tie_queries_are_the_only_ones_that_differ):
+        the p99.9 tail is held to 3 x the reference's own tail on that round (selfnoise.npz), not to a blanket constant."""
     T, H, W, k, _ = [int(v) for v in g[f"{tag}.shape"]]
+    st = int(g[f"{tag}.prob_stride"]) if f"{tag}.prob_stride" in g else 2
+    noise = load_golden("selfnoise")[tag] if k > 1 else None
     for r, (masks, prob) in enumerate(outs):
         ref_masks = g[f"{tag}.r{r}.masks"]
         if k == 1:
             ref_masks = np.unpackbits(ref_masks)[: T * H * W].reshape(T, H, W)
             assert iou(masks > 0, ref_masks > 0) >= min_iou, (tag, r)
         else:
+            # selfnoise = worst pair of the reference against ITSELF (1 / 2 / 4 / 8 threads) on this sequence.  With k > 1 the
+            # aggregation is ill-conditioned where two objects saturate (p = 1 - 1e-7 after the clamp of aggregate.py:27: the
+            # reference's own probabilities move by up to 0.13 there, 29-39 mask pixels flip).  The golden is ONE of those runs
+            # and the tested implementation another sample, per object: 3 x the envelope (measured: HIP 2.4e-3 on the worst
+            # object of seqC against an envelope of 1.16e-3); still below the 5e-3 of round 1, and k = 1 stays at 1e-3
+            bound = max(1e-3, 3 * float(noise[r][0]))
             for o in range(1, k + 1):
-                assert iou(masks == o, ref_masks == o) >= 1 - 5e-3, (tag, r, o)
-        ph = prob[:, :, 0, ::2, ::2].numpy()
+                assert 1 - iou(masks == o, ref_masks == o) <= bound, (tag, r, o, 1 - iou(masks == o, ref_masks == o), bound)
+        ph = prob[:, :, 0, ::st, ::st].numpy()
         d = np.abs(ph - g[f"{tag}.r{r}.prob_h"].astype(np.float32))
-        # fp16 storage of the golden: 5e-4 quantisation.  The top-50 membership of a query is ill-conditioned at
-        # near-ties of the 50th / 51st score: a 1e-7 rounding difference (another split-K or tile shape) can swap one
-        # member, which moves the probabilities around that query by ~1e-2 - so up to 0.5 % of the samples (a couple of
-        # query neighbourhoods) may exceed the tolerance while the masks stay within the IoU bound above.
-        assert np.quantile(d, 0.995) < prob_atol, (tag, r, float(np.quantile(d, 0.995)))
-        assert np.quantile(d, 0.999) < 0.05, (tag, r, float(np.quantile(d, 0.999)))
+        if ties is not None:
+            info = ties[r]
+            clean = sorted(info["clean"])
+            frac = info["near"] / max(info["queries"], 1)
+            worst = float(d[:, clean].max()) if clean else 0.0
+            print(f"{who} vs golden {tag} r{r}: {len(clean)} clean frames, max |dprob| on them {worst:.1e}; near-tie queries "
+                  f"{info['near']} / {info['queries']} ({100 * frac:.3f} %); all frames: max {d.max():.1e} p99.9 {np.quantile(d, 0.999):.1e}")
+            if k == 1:            # k > 1: saturated pixels (p = 1 - 1e-7 after the clamp of aggregate.py:27) are a second source
+                assert worst < clean_atol, (tag, r, worst)
+                # the reference itself (1 / 2 / 4 / 8 threads) reproduces its probabilities to < 1e-4 on this round: no
+                # near-tie is actually flipped by rounding, so an implementation must agree EVERYWHERE, on every frame
+                if float(load_golden("selfnoise")[tag][r][1]) < 1e-4:
+                    assert d.max() < clean_atol, (tag, r, float(d.max()))
+            # a re-interaction on an already interacted frame appends the same key rows again (inference_core.py:235-240):
+            # exact ties with different values by construction, the reference's own topk tie-break is unspecified there
+            script = [int(v[1]) for v in g[f"{tag}.script"]]
+            if script[r] not in script[:r]:
+                assert frac < 0.10, (tag, r, frac)      # a property of the data (denser scores at 480p: 4 %), kept in check
+        # (3) the tail, against the reference's OWN tail on this round (selfnoise: p99.9 of |prob| between its 1/2/4/8-thread
+        # runs; 6.7e-3 at 480p where 4 % of the queries are near-ties, <= 8e-4 on the small sequences): 3 x that + the fp16
+        # quantisation of the golden, and never looser than prob_atol
+        q999 = float(np.quantile(d, 0.999))
+        tail = max(prob_atol, 3 * float(load_golden("selfnoise")[tag][r][2]) + 5e-4)
+        assert q999 <= tail, (tag, r, q999, tail)
 
 
-@pytest.mark.parametrize("tag", ["seqA", "seqB", "seqC", "seqD"])
+@pytest.mark.parametrize("tag", ["seqA", "seqB", "seqC", "seqD", "seq480"])
 def test_sequence_matches_reference(tag, weights):
     g = load_golden(tag)
-    outs = run_sequence(lambda img, k, mf: O.OracleCore(weights[0], weights[1], img, k, mem_freq=mf), tag, g)
-    check_sequence_against_golden(outs, tag, g, prob_atol=2e-3)
+    cores = []
+
+    def factory(img, k, mf):
+        cores.append(O.OracleCore(weights[0], weights[1], img, k, mem_freq=mf))
+        return cores[0]
+
+    outs = run_sequence(factory, tag, g)
+    check_sequence_against_golden(outs, tag, g, prob_atol=2e-3, ties=tie_summary(cores[0]))
 
 
 def test_bank_sizes_follow_reference_formula(weights):
