@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvP p, const int
                     if (needb) {
                         const int b = p.B == 1 ? 0 : m / ohw;
                         const long po = (long)(m - b * ohw) * p.N + n;
-                        if (p.res) v += p.res[(long)b * p.res_bs + po];
+                        if (p.res) v += p.res[(long)(p.res_bmod ? b % p.res_bmod : b) * p.res_bs + po];
                         if (p.y_bs) yo = (long)b * p.y_bs + po;
                     }
                     if (p.relu_out) v = fmaxf(v, 0.f);
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256) void conv_reduce_kernel(const ConvP p) {
         if (p.res || p.y_bs) {
             const int b = p.B == 1 ? 0 : m / ohw;
             const long po = (long)(m - b * ohw) * p.N + n;
-            if (p.res) v += *reinterpret_cast<const f32x4 *>(p.res + (long)b * p.res_bs + po);
+            if (p.res) v += *reinterpret_cast<const f32x4 *>(p.res + (long)(p.res_bmod ? b % p.res_bmod : b) * p.res_bs + po);
             if (p.y_bs) yo = (long)b * p.y_bs + po;
         }
         if (p.relu_out) {
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(256) void conv_reduce_tiles_kernel(const ConvP p, c
         const int ohw = p.OH * p.OW;
         const int b = p.B == 1 ? 0 : m / ohw;
         const long po = (long)(m - b * ohw) * p.N + n;
-        if (p.res) v += *reinterpret_cast<const f32x4 *>(p.res + (long)b * p.res_bs + po);
+        if (p.res) v += *reinterpret_cast<const f32x4 *>(p.res + (long)(p.res_bmod ? b % p.res_bmod : b) * p.res_bs + po);
         if (p.y_bs) yo = (long)b * p.y_bs + po;
     }
     if (p.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }

@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void conv_gemm_f16x3_kernel(const ConvP p, con
             if (needb) {
                 const int b = p.B == 1 ? 0 : m / ohw;
                 const long po = (long)(m - b * ohw) * p.N + n;
-                if (p.res) v += p.res[(long)b * p.res_bs + po];
+                if (p.res) v += p.res[(long)(p.res_bmod ? b % p.res_bmod : b) * p.res_bs + po];
                 if (p.y_bs) yo = (long)b * p.y_bs + po;
             }
             if (p.relu_out) v = fmaxf(v, 0.f);

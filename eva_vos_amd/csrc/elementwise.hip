@@ -99,7 +99,7 @@ __device__ __forceinline__ void bil(int dst, float scale, int n, int &i0, int &i
 
 // UpsampleBlock (modules.py:159-163): u[b] = skip_conv(skip)[b * skip_bs] (skip_bs 0: batch-broadcast) + up2x(x[b])
 __global__ void upsample2x_add_kernel(const float *__restrict__ x, const float *__restrict__ skip,
-                                      float *__restrict__ u, int B, int h, int w, int C, long skip_bs) {
+                                      float *__restrict__ u, int B, int h, int w, int C, long skip_bs, int skip_bmod) {
     const int OH = 2 * h, OW = 2 * w, C4 = C / 4;
     const long i = blockIdx.x * 256L + threadIdx.x;
     if (i >= (long)B * OH * OW * C4) return;
@@ -116,7 +116,7 @@ __global__ void upsample2x_add_kernel(const float *__restrict__ x, const float *
     const f32x4 v01 = *reinterpret_cast<const f32x4 *>(xb + ((long)y0 * w + x1) * C);
     const f32x4 v10 = *reinterpret_cast<const f32x4 *>(xb + ((long)y1 * w + x0) * C);
     const f32x4 v11 = *reinterpret_cast<const f32x4 *>(xb + ((long)y1 * w + x1) * C);
-    const f32x4 sk = *reinterpret_cast<const f32x4 *>(skip + (long)b * skip_bs + ((long)oy * OW + ox) * C + c4 * 4);
+    const f32x4 sk = *reinterpret_cast<const f32x4 *>(skip + (long)(skip_bmod ? b % skip_bmod : b) * skip_bs + ((long)oy * OW + ox) * C + c4 * 4);
     const float w00 = (1.f - fy) * (1.f - fx), w01 = (1.f - fy) * fx, w10 = fy * (1.f - fx), w11 = fy * fx;
     f32x4 o;
     o.x = sk.x + (w00 * v00.x + w01 * v01.x + w10 * v10.x + w11 * v11.x);
@@ -126,9 +126,9 @@ __global__ void upsample2x_add_kernel(const float *__restrict__ x, const float *
     *reinterpret_cast<f32x4 *>(u + i * 4) = o;
 }
 void upsample2x_add_launch(const float *x, const float *skip, float *u, int B, int h, int w, int C,
-                           hipStream_t s, long skip_bs) {
+                           hipStream_t s, long skip_bs, int skip_bmod) {
     hipLaunchKernelGGL(upsample2x_add_kernel, dim3(nblocks((long)B * 4 * h * w * (C / 4))), dim3(256), 0, s, x,
-                       skip, u, B, h, w, C, skip_bs);
+                       skip, u, B, h, w, C, skip_bs, skip_bmod);
 }
 
 // aggregate_wbg (aggregate.py:22-37) on up to 8 objects: odds / sum(odds) after clamping
@@ -159,7 +159,7 @@ __device__ __forceinline__ void aggregate_store(const float *p, int k, float *ag
 
 // Decoder tail (prop_net.py:27-29,192) + aggregate: logit4 -> bilinear x4 -> sigmoid -> aggregate
 __global__ void up4_sigmoid_aggregate_kernel(const float *__restrict__ logit4, int k, int h4, int w4,
-                                             float *__restrict__ agg, long stride) {
+                                             float *__restrict__ agg, long stride, long obj_stride) {
     const int H = 4 * h4, W = 4 * w4;
     const long i = blockIdx.x * 256L + threadIdx.x;
     if (i >= (long)H * W) return;
@@ -173,7 +173,7 @@ __global__ void up4_sigmoid_aggregate_kernel(const float *__restrict__ logit4, i
     for (int o = 0; o < STCN_MAX_OBJ; ++o) {
         p[o] = 0.f;
         if (o < k) {
-            const float *l = logit4 + (long)o * h4 * w4;
+            const float *l = logit4 + (long)o * obj_stride;
             const float v = w00 * l[y0 * w4 + x0] + w01 * l[y0 * w4 + x1] + w10 * l[y1 * w4 + x0] +
                             w11 * l[y1 * w4 + x1];
             p[o] = sigmoidf_(v);
@@ -182,9 +182,9 @@ __global__ void up4_sigmoid_aggregate_kernel(const float *__restrict__ logit4, i
     aggregate_store(p, k, agg, stride, i);
 }
 void up4_sigmoid_aggregate_launch(const float *logit4, int k, int h4, int w4, float *agg, long agg_stride,
-                                  hipStream_t s) {
+                                  hipStream_t s, long obj_stride) {
     hipLaunchKernelGGL(up4_sigmoid_aggregate_kernel, dim3(nblocks(16L * h4 * w4)), dim3(256), 0, s, logit4, k, h4,
-                       w4, agg, agg_stride);
+                       w4, agg, agg_stride, obj_stride ? obj_stride : (long)h4 * w4);
 }
 
 // fusion tail (inference_core.py:203-207): sigmoid(fuse_net(...)) per object -> aggregate

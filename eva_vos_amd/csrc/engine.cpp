@@ -265,12 +265,12 @@ int Work::init(int nh, int nw, int k_, int key_batch, int group) {
     };
     const size_t s1 = (size_t)k * d.hw2 * 64, s2 = (size_t)d.npix * 32, s3 = (size_t)k * d.hw4 * 256;
     const size_t s4 = (size_t)key_batch * d.hw2 * 64;          // batched key encoder
-    const size_t s5 = (size_t)group * d.hw4 * 256;             // batched decoder (k == 1)
+    const size_t s5 = (size_t)group * k * d.hw4 * 256;         // batched decoder: objects x frames of a decode group
     S = s1 > s2 ? s1 : s2;
     S = S > s3 ? S : s3;
     S = S > s4 ? S : s4;
     S = S > s5 ? S : s5;
-    const int kg = k > group ? k : group;                      // per-(object | frame) buffers of the decoder
+    const int kg = k * group;                                  // per-(object, frame) buffers of the decoder
     int rc;
     for (float **b : {&A, &B, &C, &D})
         if ((rc = alloc((void **)b, S * sizeof(float)))) return rc;
@@ -312,7 +312,7 @@ int launch_status(const char *what) {
 
 int run_conv(const Model &m, Work &w, hipStream_t s, const char *name, const float *x0, int c0, long bs0,
              const float *x1, int c1, long bs1, int B, int H, int W, int stride, float *y, long y_bs,
-             const float *res, long res_bs, int relu_in, int relu_out, int force_splitk) {
+             const float *res, long res_bs, int relu_in, int relu_out, int force_splitk, int res_bmod) {
     auto it = m.conv.find(name);
     if (it == m.conv.end()) { set_error("missing conv '%s'", name); return STCN_E_MISSING; }
     const ConvW &cw = it->second;
@@ -337,7 +337,7 @@ int run_conv(const Model &m, Work &w, hipStream_t s, const char *name, const flo
     if (x1 && ((cw.cin_p % 32) || (c0 % 32) || cw.kh * cw.kw > 32)) { set_error("conv '%s': two-source input needs 32-aligned channel splits", name); return STCN_E_INVALID; }
     p.w = cw.w; p.w_hi = cw.w_hi; p.w_lo = cw.w_lo; p.oscale = cw.oscale;
     p.mode = ((m.precision & 1) && cw.w_hi) ? 1 : 0;
-    p.bias = cw.bias; p.res = res; p.res_bs = res_bs; p.y = y; p.y_bs = y_bs;
+    p.bias = cw.bias; p.res = res; p.res_bs = res_bs; p.res_bmod = res_bmod; p.y = y; p.y_bs = y_bs;
     p.relu_in = relu_in; p.relu_out = relu_out;
     p.partial = w.splitk;
     conv_plan(p, force_splitk, w.splitk_floats);
@@ -508,24 +508,27 @@ int decode(const Model &m, Work &w, hipStream_t s, const float *readout, const f
            const float *s4, float *agg, long agg_stride, const float *dthin, const float *cthin, int G, long slot_bs) {
     const Dims &d = w.d;
     const int k = w.k;
-    if (G > 1 && (k != 1 || !dthin || !cthin)) { set_error("decode: frame batches need k == 1 and cached frame parts"); return STCN_E_INVALID; }
-    const int B = G > 1 ? G : k;                 // batch = objects of one frame, or frames of one object
-    const long fbs = G > 1 ? slot_bs : 0;        // per-frame inputs: one per batch element, or broadcast over the objects
+    if (G > 1 && (!dthin || !cthin)) { set_error("decode: frame batches need the cached frame parts"); return STCN_E_INVALID; }
+    // batch = the objects of one frame, or (G > 1) objects x frames laid out [object][frame]: element b belongs to frame
+    // b % G, whose per-frame inputs (frame parts of decoder.compress, skip convs) sit G cache slots apart
+    const int B = G > 1 ? G * k : k;
+    const long fbs = G > 1 ? slot_bs : 0;        // per-frame inputs: one per frame of the group, or broadcast over the objects
+    const int bmod = G > 1 && k > 1 ? G : 0;
     if (dthin && cthin) {
         const std::string p = "decoder.compress";
         const ConvW &cw = m.c(p + ".conv1");
         const long obs = (long)d.hw16 * cw.cout, xbs = (long)d.hw16 * 512;
-        RC(run_conv(m, w, s, (p + ".downsample#a").c_str(), readout, 512, xbs, nullptr, 0, 0, B, d.h16, d.w16, 1, w.D, 0, dthin, fbs, 0, 0));
-        RC(run_conv(m, w, s, (p + ".conv1#a").c_str(), readout, 512, xbs, nullptr, 0, 0, B, d.h16, d.w16, 1, w.C, 0, cthin, fbs, 1, 1));
+        RC(run_conv(m, w, s, (p + ".downsample#a").c_str(), readout, 512, xbs, nullptr, 0, 0, B, d.h16, d.w16, 1, w.D, 0, dthin, fbs, 0, 0, 0, bmod));
+        RC(run_conv(m, w, s, (p + ".conv1#a").c_str(), readout, 512, xbs, nullptr, 0, 0, B, d.h16, d.w16, 1, w.C, 0, cthin, fbs, 1, 1, 0, bmod));
         RC(run_conv(m, w, s, (p + ".conv2").c_str(), w.C, cw.cout, obs, nullptr, 0, 0, B, d.h16, d.w16, 1, w.A, 0, w.D, obs, 0, 0));
     } else {
         RC(resblock(m, w, s, "decoder.compress", readout, 512, (long)d.hw16 * 512, f16_thin, 512, 0, k, d.h16, d.w16, w.C,
                     w.D, w.A, 0));
     }
-    { Scope sc(w.prof, STCN_K_ELEMWISE, s); upsample2x_add_launch(w.A, s8, w.B, B, d.h16, d.w16, 512, s, fbs); }
+    { Scope sc(w.prof, STCN_K_ELEMWISE, s); upsample2x_add_launch(w.A, s8, w.B, B, d.h16, d.w16, 512, s, fbs, bmod); }
     RC(resblock(m, w, s, "decoder.up_16_8.out_conv", w.B, 512, (long)d.hw8 * 512, nullptr, 0, 0, B, d.h8, d.w8, w.C, w.D,
                 w.A, 0));
-    { Scope sc(w.prof, STCN_K_ELEMWISE, s); upsample2x_add_launch(w.A, s4, w.B, B, d.h8, d.w8, 256, s, fbs); }
+    { Scope sc(w.prof, STCN_K_ELEMWISE, s); upsample2x_add_launch(w.A, s4, w.B, B, d.h8, d.w8, 256, s, fbs, bmod); }
     RC(resblock(m, w, s, "decoder.up_8_4.out_conv", w.B, 256, (long)d.hw4 * 256, nullptr, 0, 0, B, d.h4, d.w4, w.C, w.D,
                 w.A, 0));
     const ConvW &pw = m.c("decoder.pred");
@@ -535,13 +538,14 @@ int decode(const Model &m, Work &w, hipStream_t s, const float *readout, const f
     }
     {
         Scope sc(w.prof, STCN_K_ELEMWISE, s);
-        if (G > 1)
+        if (G > 1)                               // frame g: its k objects are G planes apart; agg [G][k+1][npix]
             for (int g = 0; g < G; ++g)
-                up4_sigmoid_aggregate_launch(w.logit4 + (size_t)g * d.hw4, 1, d.h4, d.w4, agg + (size_t)g * 2 * agg_stride, agg_stride, s);
+                up4_sigmoid_aggregate_launch(w.logit4 + (size_t)g * d.hw4, k, d.h4, d.w4, agg + (size_t)g * (k + 1) * agg_stride, agg_stride, s,
+                                             (long)G * d.hw4);
         else
             up4_sigmoid_aggregate_launch(w.logit4, k, d.h4, d.w4, agg, agg_stride, s);
     }
-    return STCN_OK;
+    return launch_status("decoder tail");
 }
 
 // FusionNet.forward (fusion_net.py:32-50) for one object
@@ -687,8 +691,9 @@ static int engine_alloc_common(stcn_engine *e) {
     const char *gb = getenv("STCN_DECODE_BATCH");
     e->group = gb ? atoi(gb) : 8;
     if (e->group > e->mem_freq) e->group = e->mem_freq;      // a group ends at the next bank insertion
-    if (e->group < 1 || e->k != 1) e->group = 1;
+    if (e->group < 1) e->group = 1;
     if (e->group > 8) e->group = 8;
+    while (e->group > 1 && e->group * e->k > 16) --e->group;   // objects x frames per decoder pass (workspace ~ 0.1 GB each)
     const char *kb = getenv("STCN_KEY_BATCH");
     e->key_batch = kb ? atoi(kb) : (e->group > 4 ? e->group : 4);   // a decode group is key-encoded in one pass
     if (e->key_batch < 1) e->key_batch = 1;
@@ -928,7 +933,7 @@ static void dbg_sum(stcn_engine *e, const char *tag, int ti, const float *p, siz
 
 // do_pass (inference_core.py:126-191).  A frame's segmentation depends on its own key features and on the memory bank
 // only, and the bank changes only when a frame is inserted (every mem_freq-th): the frames up to and including the
-// next insertion are independent of each other, so (for k == 1) their memory reads and decoder passes run as ONE batch
+// next insertion are independent of each other, so their memory reads and decoder passes run as ONE batch (objects x frames)
 // of up to `group` frames - 5x the rows per implicit GEMM at mem_freq = 5, 1/5 of the launches.
 static int do_pass(stcn_engine *e, int idx, bool forward) {
     const Dims &d = e->d;
@@ -949,7 +954,7 @@ static int do_pass(stcn_engine *e, int idx, bool forward) {
     while (ti != closest) {
         // ---- the group: ti and the following frames up to and including the next bank insertion
         int G = 1;
-        const int gmax = k == 1 ? e->group : 1;
+        const int gmax = e->group;
         auto inserts = [&](int t) { return t != end && std::abs(t - last_ti) >= e->mem_freq; };
         while (G < gmax && !inserts(ti + (G - 1) * step) && ti + G * step != closest) ++G;
         std::vector<SlotPtrs> kf(G);
@@ -990,9 +995,9 @@ static int do_pass(stcn_engine *e, int idx, bool forward) {
                 copy_rows_launch(f0.k16, (long)e->slot_floats, w.qk, (long)d.hw16 * 64, G, (long)d.hw16 * 64, e->stream);
             }
             {
-                Scope sc(&e->prof, STCN_K_MEMREAD, e->stream, G * (2.0 * N * d.hw16 * 64 + 2.0 * d.hw16 * 50 * 512));
-                e->prof.bytes[STCN_K_MEMREAD] += memread_bytes(N, G * d.hw16, 1);
-                memory_read_launch(e->bank_k, e->bank_msq, w.qk, N, G * d.hw16, e->bank_v, (long)e->bank_cap * d.hw16 * 512, 1,
+                Scope sc(&e->prof, STCN_K_MEMREAD, e->stream, G * (2.0 * N * d.hw16 * 64 + 2.0 * k * d.hw16 * 50 * 512));
+                e->prof.bytes[STCN_K_MEMREAD] += memread_bytes(N, G * d.hw16, k);
+                memory_read_launch(e->bank_k, e->bank_msq, w.qk, N, G * d.hw16, e->bank_v, (long)e->bank_cap * d.hw16 * 512, k,
                                    w.readout, (long)G * d.hw16 * 512, nullptr, nullptr, MemReadScratch{w.cand_v, w.cand_i, w.cand_n, w.gmax, w.tau},
                                    e->stream);
             }

@@ -105,7 +105,7 @@ struct KeyOut { float *k16, *msq, *f16_thin, *f16, *s8, *s4, *f8_copy, *f4_copy,
 int launch_status(const char *what);     // STCN_OK, or STCN_E_HIP with the failing launch class in the error string
 int run_conv(const Model &m, Work &w, hipStream_t s, const char *name, const float *x0, int c0, long bs0,
              const float *x1, int c1, long bs1, int B, int H, int W, int stride, float *y, long y_bs,
-             const float *res, long res_bs, int relu_in, int relu_out, int force_splitk = 0);
+             const float *res, long res_bs, int relu_in, int relu_out, int force_splitk = 0, int res_bmod = 0);
 // B consecutive frames at once; outputs of frame b at o.<ptr> + b * out_bs
 int encode_key(const Model &m, Work &w, hipStream_t s, const float *img4, const KeyOut &o, int B = 1, long out_bs = 0);
 // vd / vc: cached frame-only halves of fuser.block1 (nullptr: compute the full two-source convs)
@@ -114,8 +114,8 @@ int encode_value(const Model &m, Work &w, hipStream_t s, const float *img4, cons
                  const float *vc = nullptr);
 int value_frame_parts(const Model &m, Work &w, hipStream_t s, const float *f16, float *vd, float *vc);
 // dthin / cthin: cached frame-only halves of decoder.compress (nullptr: full two-source convs)
-// G > 1 (k == 1 only): G frames at once - readout [G][hw16][512], agg [G][2][npix], the per-frame inputs of frame g at
-// <ptr> + g * slot_bs (consecutive key-cache slots)
+// G > 1: G frames at once, batch laid out [object][frame] - readout [k][G][hw16][512] (what one memory read of G * hw16
+// queries writes), agg [G][k+1][npix], the per-frame inputs of frame g at <ptr> + g * slot_bs (consecutive key-cache slots)
 int decode(const Model &m, Work &w, hipStream_t s, const float *readout, const float *f16_thin,
            const float *s8, const float *s4, float *agg, long agg_stride, const float *dthin = nullptr,
            const float *cthin = nullptr, int G = 1, long slot_bs = 0);

@@ -25,6 +25,8 @@ struct ConvP {
     const float *bias;      // [N] or nullptr
     const float *res;       // residual [B][OH*OW][N] or nullptr
     long res_bs;            // batch stride of res (0 = broadcast)
+    int res_bmod;           // > 0: the residual of batch element b is res + (b % res_bmod) * res_bs (a per-FRAME tensor under a
+                            // batch laid out [object][frame]: decode groups of multi-object engines)
     float *y;               // [M][N]
     long y_bs;              // output batch stride in elements (0 = dense OH*OW*N)
     int relu_in, relu_out;
@@ -61,11 +63,13 @@ void pack_image_launch(const float *img_chw, float *out, int H, int W, int nh, i
 void pack_value_input_launch(const float *img4, const float *masks, long mask_stride, int k, int npix,
                              float *out, hipStream_t s);
 // u[b] = skip[b * skip_bs] (skip_bs 0: broadcast over b) + bilinear_up2x(x[b]); x [B,h,w,C] -> u [B,2h,2w,C]
+// skip_bmod > 0: the skip of batch element b is skip + (b % skip_bmod) * skip_bs
 void upsample2x_add_launch(const float *x, const float *skip, float *u, int B, int h, int w, int C,
-                           hipStream_t s, long skip_bs = 0);
+                           hipStream_t s, long skip_bs = 0, int skip_bmod = 0);
 // logit4 [k,h4*w4] -> bilinear x4 -> sigmoid -> aggregate_wbg -> agg [k+1][nh*nw] (row stride agg_stride)
+// obj_stride: floats between the logit planes of consecutive objects (0 = h4*w4)
 void up4_sigmoid_aggregate_launch(const float *logit4, int k, int h4, int w4, float *agg,
-                                  long agg_stride, hipStream_t s);
+                                  long agg_stride, hipStream_t s, long obj_stride = 0);
 // logits [k,npix] -> sigmoid -> aggregate -> agg rows (fusion output)
 void sigmoid_aggregate_launch(const float *logit, int k, long npix, float *agg, long agg_stride,
                               hipStream_t s);

@@ -154,9 +154,12 @@ def test_full_resolution_two_rounds_match_the_oracle(nets, weights):
         d = (core.prob.cpu() - orc.prob).abs().numpy()
         q = [float(np.quantile(d, v)) for v in (0.5, 0.99, 0.999)]
         print(f"full-res round idx={idx}: |prob diff| median {q[0]:.1e} q99 {q[1]:.1e} q999 {q[2]:.1e} max {d.max():.1e}")
-        # ~1620 queries x top-50 over thousands of bank rows: a few near-tie memberships differ between two fp32
-        # implementations (see check_sequence_against_golden); the bulk agrees to 1e-3
-        assert q[1] < 2e-3 and q[2] < 5e-2, (idx, q)
+        # 4 % of the 1620 queries per frame are near-ties at this resolution (tie_summary above): a few memberships differ
+        # between two fp32 implementations.  The yardstick is the REFERENCE against itself at this resolution (seq480 in
+        # tests/golden/selfnoise.npz: p99.9 of |prob| between its 1/2/4/8-thread runs = 6.7e-3 / 7.2e-3): 3 x that for the
+        # tail, the bulk (p99) within 2e-3
+        floor = float(load_golden("selfnoise")["seq480"][r][2])
+        assert q[1] < 2e-3 and q[2] < 3 * floor, (idx, q, floor)
     assert core.stats()["fused"] == 4
     gt = msk[0, :, 0].numpy() > 0.5
     jf_gpu = metrics.sequence_scores_gpu(torch.from_numpy(gt).cuda(), torch.from_numpy(a > 0).cuda())
