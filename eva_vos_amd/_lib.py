@@ -14,7 +14,7 @@ import torch  # noqa: F401  (first: PyTorch-ROCm bundles its own libamdhip64/lib
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libstcn_hip.so")
 
-K_CLASSES = ("conv", "conv_reduce", "memread", "elementwise", "conv_n1", "other")
+K_CLASSES = ("conv", "conv_reduce", "memread", "elementwise", "conv_n1", "other", "wino_input")
 
 
 class WeightDesc(C.Structure):
@@ -54,6 +54,7 @@ PROTOTYPES = {
     "stcn_get_kernel_ms": (_I, [_P, C.POINTER(_F), C.POINTER(C.c_int32)]),
     "stcn_get_kernel_flops": (_I, [_P, C.POINTER(_D)]),
     "stcn_get_kernel_bytes": (_I, [_P, C.POINTER(_D)]),
+    "stcn_get_kernel_exec_flops": (_I, [_P, C.POINTER(_D)]),
     "stcn_get_conv_regimes": (_I, [_P, C.POINTER(_D)]),
 }
 

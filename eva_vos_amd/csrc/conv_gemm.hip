@@ -544,14 +544,18 @@ void conv_launch(const ConvP &p, hipStream_t s, hipEvent_t *ev_gemm, hipEvent_t 
         else
             hipLaunchKernelGGL(conv_reduce_tiles_kernel, dim3(blocks), dim3(256), 0, s, p, tiles_n, ntile, BM, BN);
     } else if (p.splitk > 1) {
-        const long total4 = (long)p.M * p.N / 4;
-        long blocks = (total4 + 255) / 256;
-        if (blocks > 2048) blocks = 2048;
-        if (ev_red)
-            hipExtLaunchKernelGGL(conv_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, ev_red[0], ev_red[1], 0, p);
-        else
-            hipLaunchKernelGGL(conv_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
+        conv_reduce_launch(p, s, ev_red);
     }
+}
+
+void conv_reduce_launch(const ConvP &p, hipStream_t s, hipEvent_t *ev_red) {
+    const long total4 = (long)p.M * p.N / 4;
+    long blocks = (total4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (ev_red)
+        hipExtLaunchKernelGGL(conv_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, ev_red[0], ev_red[1], 0, p);
+    else
+        hipLaunchKernelGGL(conv_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -23,7 +23,7 @@ const char *get_error() { return g_err; }
 
 // ---------------------------------------------------------------------------------------------- Prof
 void Prof::reset() {
-    for (int i = 0; i < STCN_K_COUNT; ++i) { flops[i] = 0; bytes[i] = 0; launches[i] = 0; }
+    for (int i = 0; i < STCN_K_COUNT; ++i) { flops[i] = 0; bytes[i] = 0; exec_flops[i] = 0; launches[i] = 0; }
     hbm_conv_flops = hbm_conv_bytes = hbm_conv_ms = 0; hbm_conv_launches = 0;
     for (auto &e : events) { pool.push_back(e.a); pool.push_back(e.b); }
     events.clear();
@@ -120,6 +120,14 @@ int make_f16_split(Model &m, ConvW &cw, const std::vector<float> &w) {
     return upload(m, osc, &cw.oscale);
 }
 
+int make_wino(Model &m, ConvW &cw, const std::vector<float> &w) {
+    static const bool on = [] { const char *e = getenv("STCN_WINOGRAD"); return !e || atoi(e) != 0; }();
+    if (!on || cw.kh != 3 || cw.kw != 3 || cw.cin_p % 8 || cw.cin_p < 128 || cw.cout % 64 || (m.precision & 1)) return STCN_OK;
+    std::vector<float> u((size_t)16 * cw.cin_p * cw.cout);
+    wino_transform_weights(w.data(), cw.cout, cw.cin_p, cw.Kp, u.data());
+    return upload(m, u, &cw.wino_u);
+}
+
 static int add_convs(Model &m, const std::map<std::string, HostT> &sd) {
     for (auto &kv : sd) {
         const std::string &name = kv.first;
@@ -163,6 +171,7 @@ static int add_convs(Model &m, const std::map<std::string, HostT> &sd) {
         rc = upload(m, bias, &cw.bias);
         if (rc) return rc;
         if ((m.precision & 1) && cout > 1 && (rc = make_f16_split(m, cw, w))) return rc;
+        if ((rc = make_wino(m, cw, w))) return rc;
         cw.bias0 = bias[0];
         m.conv[pre] = cw;
         // Convs over a channel concat [per-object part | frame-only part]: conv is linear in the input
@@ -188,6 +197,7 @@ static int add_convs(Model &m, const std::map<std::string, HostT> &sd) {
                 std::vector<float> bb = part ? bias : std::vector<float>(cout, 0.f);
                 if ((rc = upload(m, ww, &pw.w)) || (rc = upload(m, bb, &pw.bias))) return rc;
                 if ((m.precision & 1) && (rc = make_f16_split(m, pw, ww))) return rc;
+                if ((rc = make_wino(m, pw, ww))) return rc;
                 pw.bias0 = bb[0];
                 m.conv[pre + (part ? "#b" : "#a")] = pw;
             }
@@ -276,6 +286,14 @@ int Work::init(int nh, int nw, int k_, int key_batch, int group) {
         if ((rc = alloc((void **)b, S * sizeof(float)))) return rc;
     splitk_floats = (size_t)32 * 1024 * 1024;      // 128 MB of fp32 slabs; conv falls back to fewer splits
     if ((rc = alloc((void **)&splitk, splitk_floats * sizeof(float)))) return rc;
+    {   // Winograd V of the largest 3x3 conv this workspace serves: 256 channels at 1/4 scale over the largest batch
+        static const bool wino = [] { const char *e = getenv("STCN_WINOGRAD"); return !e || atoi(e) != 0; }();
+        int maxb = key_batch > k * group ? key_batch : k * group;
+        const long mt = ((long)maxb * ((d.h4 + 1) / 2) * ((d.w4 + 1) / 2) + 63) / 64 * 64;
+        wino_v_floats = wino ? (size_t)16 * 256 * mt : 0;
+        if (wino_v_floats * 4 >= ((size_t)1 << 32)) wino_v_floats = ((size_t)1 << 30) - 64;      // 32-bit offsets: larger convs run direct
+        if (wino_v_floats && (rc = alloc((void **)&wino_v, wino_v_floats * sizeof(float)))) return rc;
+    }
     if ((rc = alloc((void **)&cbam, (size_t)k * (16 * 1024 + 512 + 3 * d.hw16) * sizeof(float)))) return rc;
     if ((rc = alloc((void **)&readout, (size_t)kg * d.hw16 * 512 * sizeof(float)))) return rc;
     if ((rc = alloc((void **)&logit4, (size_t)kg * d.hw4 * sizeof(float)))) return rc;
@@ -335,14 +353,18 @@ int run_conv(const Model &m, Work &w, hipStream_t s, const char *name, const flo
     p.x1_bytes = (unsigned)x1b;
     p.w_bytes = (unsigned)((long)cw.cout * cw.Kp * 4);
     if (x1 && ((cw.cin_p % 32) || (c0 % 32) || cw.kh * cw.kw > 32)) { set_error("conv '%s': two-source input needs 32-aligned channel splits", name); return STCN_E_INVALID; }
-    p.w = cw.w; p.w_hi = cw.w_hi; p.w_lo = cw.w_lo; p.oscale = cw.oscale;
+    p.w = cw.w; p.w_hi = cw.w_hi; p.w_lo = cw.w_lo; p.oscale = cw.oscale; p.wino_u = cw.wino_u;
     p.mode = ((m.precision & 1) && cw.w_hi) ? 1 : 0;
     p.bias = cw.bias; p.res = res; p.res_bs = res_bs; p.res_bmod = res_bmod; p.y = y; p.y_bs = y_bs;
     p.relu_in = relu_in; p.relu_out = relu_out;
     p.partial = w.splitk;
     conv_plan(p, force_splitk, w.splitk_floats);
     const double fl = 2.0 * p.M * p.N * (double)(cw.kh * cw.kw * cw.cin);
-    hipEvent_t *eg = nullptr, *er = nullptr;
+    // stride-1 3x3 convs run as Winograd F(2x2,3x3) (2.25x fewer MFMA FLOP, exact-fp32 arithmetic) unless a split-K is forced
+    const size_t wino_need = force_splitk > 0 ? 0 : wino_workspace_floats(p);
+    const bool wino = wino_need > 0 && wino_need <= w.wino_v_floats;
+    const double fl_exec = wino ? 2.0 * (double)(wino_need / cw.cin_p) * cw.cin_p * p.N : fl;
+    hipEvent_t *eg = nullptr, *er = nullptr, *ei = nullptr;
     if (w.prof) {
         // algorithmic bytes: the input tensors (dense data, not the descriptor extents; a broadcast source once), weights,
         // output and residual (a broadcast residual once), each once
@@ -353,11 +375,18 @@ int run_conv(const Model &m, Work &w, hipStream_t s, const char *name, const flo
         const bool hbm_bound = fl / bytes < 157.3e12 / 8.0e12;
         w.prof->bytes[STCN_K_CONV] += bytes;
         w.prof->flops[STCN_K_CONV] += fl;
+        w.prof->exec_flops[STCN_K_CONV] += fl_exec;
         if (hbm_bound) { w.prof->hbm_conv_bytes += bytes; w.prof->hbm_conv_flops += fl; }
         eg = w.prof->attach(STCN_K_CONV, hbm_bound);
-        if (p.splitk > 1 || p.rem_split > 1) er = w.prof->attach(STCN_K_CONV_REDUCE);
+        if (wino) {
+            ei = w.prof->attach(STCN_K_WINO_INPUT);
+            if (wino_plan_splitk(p, w.splitk_floats) > 1) er = w.prof->attach(STCN_K_CONV_REDUCE);
+        } else if (p.splitk > 1 || p.rem_split > 1) {
+            er = w.prof->attach(STCN_K_CONV_REDUCE);
+        }
     }
-    conv_launch(p, s, eg, er);
+    if (wino) wino_launch(p, w.wino_v, w.splitk_floats, s, ei, eg, er);
+    else conv_launch(p, s, eg, er);
     return launch_status(name);
 }
 
@@ -1118,6 +1147,11 @@ int stcn_get_kernel_ms(const stcn_engine *e, float *ms, int32_t *launches) {
 int stcn_get_kernel_flops(const stcn_engine *e, double *flops) {
     if (!e || !flops) return STCN_E_INVALID;
     for (int i = 0; i < STCN_K_COUNT; ++i) flops[i] = e->prof.flops[i];
+    return STCN_OK;
+}
+int stcn_get_kernel_exec_flops(const stcn_engine *e, double *flops) {
+    if (!e || !flops) return STCN_E_INVALID;
+    for (int i = 0; i < STCN_K_COUNT; ++i) flops[i] = e->prof.exec_flops[i];
     return STCN_OK;
 }
 int stcn_get_kernel_bytes(const stcn_engine *e, double *bytes) {

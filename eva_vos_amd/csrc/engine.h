@@ -19,6 +19,8 @@ struct Model;
 struct ConvW;
 // builds the fp16 hi / lo weight arrays + output scales of one conv from its repacked fp32 host weights
 int make_f16_split(Model &m, ConvW &cw, const std::vector<float> &w_host);
+// builds the Winograd weights of a stride-1-capable 3x3 conv from its repacked fp32 host weights (no-op when not eligible)
+int make_wino(Model &m, ConvW &cw, const std::vector<float> &w_host);
 #define HIPCHK(x)                                                                          \
     do {                                                                                   \
         hipError_t e_ = (x);                                                               \
@@ -32,6 +34,7 @@ struct ConvW {
     float *w = nullptr, *bias = nullptr;   // device: [Cout][Kp], [Cout]
     uint16_t *w_hi = nullptr, *w_lo = nullptr;   // device: fp16 hi/lo of 2^s_n * w (f16x3 mode)
     float *oscale = nullptr;               // device: [Cout] 2^-s_n / 4
+    float *wino_u = nullptr;               // device: Winograd F(2x2,3x3) weights [16][Cin/8][Cout][8] (eligible 3x3 convs)
     float bias0 = 0.f;                     // host copy of bias[0] (Cout == 1 convs)
     int cout = 0, cin = 0, cin_p = 0, kh = 0, kw = 0, K = 0, Kp = 0;
 };
@@ -62,6 +65,7 @@ struct Prof {
     bool on = false;
     double flops[STCN_K_COUNT] = {0};
     double bytes[STCN_K_COUNT] = {0};     // algorithmic HBM bytes (each operand once)
+    double exec_flops[STCN_K_COUNT] = {0};   // FLOP the matrix cores executed (Winograd convs: 2.25x fewer than algorithmic)
     int launches[STCN_K_COUNT] = {0};
     struct Ev { int cls; bool hbm; hipEvent_t a, b; };    // a, b contiguous: attach() hands out &a as hipEvent_t[2]
     std::deque<Ev> events;                      // deque: attach() returns pointers into it
@@ -84,6 +88,7 @@ struct Work {
     size_t S = 0;                       // floats per big buffer
     float *A = nullptr, *B = nullptr, *C = nullptr, *D = nullptr;
     float *splitk = nullptr; size_t splitk_floats = 0;
+    float *wino_v = nullptr; size_t wino_v_floats = 0;   // Winograd-transformed input of the conv in flight
     float *cbam = nullptr;
     float *readout = nullptr;           // [k][hw16][512]
     float *logit4 = nullptr;            // [k][hw4]

@@ -48,12 +48,22 @@ int stcn_test_conv(void *stream, const float *x, const float *wgt, const float *
         HIPCHK(hipMemcpy(hw.data(), wpad.p, hw.size() * 4, hipMemcpyDeviceToHost));
         RC(make_f16_split(m, cw, hw));
     }
-    m.conv["t"] = cw;
+    const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
     Work w;
+    DevBuf wv;
+    if (m.precision == 0 && KH == 3 && stride == 1) {          // stride-1 3x3: the Winograd path, as in the engine
+        HIPCHK(hipStreamSynchronize(s));
+        std::vector<float> hw((size_t)Cout * cw.Kp);
+        HIPCHK(hipMemcpy(hw.data(), wpad.p, hw.size() * 4, hipMemcpyDeviceToHost));
+        RC(make_wino(m, cw, hw));
+        w.wino_v_floats = (size_t)16 * Cin * (((size_t)B * ((OH + 1) / 2) * ((OW + 1) / 2) + 63) / 64 * 64);
+        RC(wv.alloc(w.wino_v_floats));
+        w.wino_v = wv.p;
+    }
+    m.conv["t"] = cw;
     w.splitk_floats = (size_t)16 * 1024 * 1024;
     RC(ws.alloc(w.splitk_floats));
     w.splitk = ws.p;
-    const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
     if (Cout == 1) {
         if (stride != 1) { set_error("Cout==1 path is stride 1"); return STCN_E_INVALID; }
         float b0 = 0.f;
@@ -95,8 +105,15 @@ int stcn_bench_conv(void *stream, int B, int H, int W, int Cin, int Cout, int KH
     m.precision = (prec && std::string(prec) == "f16x3" && Cout > 1) ? 1 : 0;
     struct Guard { Model &m; ~Guard() { (void)hipDeviceSynchronize(); for (void *p : m.allocs) (void)hipFree(p); } } guard{m};
     if (m.precision == 1) RC(make_f16_split(m, cw, h));
-    m.conv["t"] = cw;
     Work w;
+    DevBuf wv;
+    if (m.precision == 0 && KH == 3 && stride == 1) {
+        RC(make_wino(m, cw, h));
+        w.wino_v_floats = (size_t)16 * Cin * (((size_t)B * ((OH + 1) / 2) * ((OW + 1) / 2) + 63) / 64 * 64);
+        RC(wv.alloc(w.wino_v_floats));
+        w.wino_v = wv.p;
+    }
+    m.conv["t"] = cw;
     w.splitk_floats = (size_t)32 * 1024 * 1024;
     RC(ws.alloc(w.splitk_floats));
     w.splitk = ws.p;

@@ -36,6 +36,7 @@ struct ConvP {
     // cut into rem_split K pieces of rem_per K tiles whose tile-local partial sums go to `partial`
     // ([(tile - rem_full) * rem_split + piece][BM][BN]) and are summed by conv_reduce_tiles_kernel
     int rem_full, rem_split, rem_per;
+    const float *wino_u;    // Winograd-transformed weights [16][Cin/8][N][8] (stride-1 3x3 convs with Cin >= 64, N % 64 == 0) or nullptr
     int tile_big;           // 1 = 128x128 workgroup tiles (fp32 kernel)
     int panel;              // > 0: tiles are walked in panels of this many n-tiles (fp32 kernel)
 };
@@ -45,6 +46,14 @@ void conv_plan(ConvP &p, int force_splitk, size_t workspace_floats);
 // ev_gemm / ev_red: optional {start, stop} event pairs attached to the GEMM / reduce dispatches themselves
 // (hipExtLaunchKernelGGL: kernel begin/end timestamps, no extra barrier packets)
 void conv_launch(const ConvP &p, hipStream_t s, hipEvent_t *ev_gemm = nullptr, hipEvent_t *ev_red = nullptr);
+// split-K tail of a conv whose slabs p.partial [p.splitk][M][N] are filled: sum + bias / residual / ReLU -> y
+void conv_reduce_launch(const ConvP &p, hipStream_t s, hipEvent_t *ev_red = nullptr);
+// Winograd F(2x2,3x3) path (winograd.hip): V workspace floats this conv needs, or 0 when it is not eligible
+size_t wino_workspace_floats(const ConvP &p);
+void wino_launch(const ConvP &p, float *V, size_t slab_floats, hipStream_t s, hipEvent_t *ev_in = nullptr, hipEvent_t *ev_gemm = nullptr,
+                 hipEvent_t *ev_red = nullptr);
+int wino_plan_splitk(const ConvP &p, size_t slab_floats);
+void wino_transform_weights(const float *w, int N, int Cin, int Kp, float *U);
 void conv_f16x3_launch(const ConvP &p, int tiles_n, int ntile, int per, dim3 grid, hipStream_t s, hipEvent_t e0,
                        hipEvent_t e1);
 static constexpr float CONV_F16_ASCALE = 4.f;

@@ -1,0 +1,338 @@
+// winograd.hip - fp32 Winograd F(2x2, 3x3) for the stride-1 3x3 convolutions of the STCN path on gfx950.
+//
+// 199 of the 290 GFLOP of a propagated frame are stride-1 3x3 convs (decoder ResBlocks, skip convs, key_comp, the 3x3 of the
+// ResNet blocks: reference mivos/model/propagation/{prop_net.py:13-30, modules.py:15-52, mod_resnet.py}).  F(2x2,3x3) computes a
+// 2x2 output tile from a 4x4 input tile with 16 multiplies per (cin, cout) instead of 36: 2.25x fewer MFMA FLOP, still exact-fp32
+// arithmetic (the transforms only add / subtract / halve).
+//     V = B^T d B   (4x4 input tile d, per channel)          U = G g G^T   (3x3 filter g, per (cout, cin); host, once per model)
+//     M[xi][nu] = sum_cin U[xi][nu] V[xi][nu]                Y = A^T M A   (2x2 outputs)
+// Structure (what the measurements of the direct kernel dictated: the fp32 MFMA shares issue with VALU, so no transform
+// arithmetic may sit in the MFMA loop, and the 4x-sized transformed output must never travel through HBM):
+//   * wino_input_kernel : X -> V, HBM-bound.  V is laid out [16 positions][C/8 k-blocks][tiles][8 floats] so that the MFMA A
+//     fragment of (position, k-block) for 32 consecutive tiles is ONE contiguous KB: 64 lanes x 16 B, fully coalesced.
+//     U has the same layout over output channels.
+//   * wino_gemm_kernel  : one workgroup = 64 tiles x 64 output channels x ALL 16 positions, 8 waves, each wave 2 positions x
+//     (2 x 2) blocks of v_mfma_f32_32x32x2_f32.  Positions are private to a wave, so no operand is shared between waves:
+//     the main loop has NO LDS and NO barrier - every wave streams its own fragments global -> registers with buffer loads
+//     (loop-invariant per-lane offsets + one scalar k-block offset: no address VALU), one k-block ahead.
+//     8 x 16-byte loads per 32 MFMAs = 16 B per CU-cycle from L2, the same as the 64x64 direct tile.
+//   * epilogue: the 16 positions of a tile meet in LDS (128 KB, 32 output channels at a time), Y = A^T M A, + bias / residual /
+//     ReLU, 128-byte coalesced stores.  Split-K over input channels (few tiles) writes transformed partial sums into the slabs
+//     of conv_reduce_kernel (the output transform is linear).
+#include <hip/hip_ext.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+
+#include "kernels.h"
+
+namespace stcn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static constexpr int WT = 64;        // tiles per workgroup
+static constexpr int WN = 64;        // output channels per workgroup
+
+// ------------------------------------------------------------------------------------------------ input transform
+// thread = (tile, half h of an 8-channel k-block); loops over the k-blocks of its chunk (blockIdx.y)
+__global__ __launch_bounds__(256) void wino_input_kernel(const float *__restrict__ x, long x_bs, int H, int W, int C, int relu_in,
+                                                         int TH, int TW, int Mt, int Mt_pad, int kb_per_chunk,
+                                                         float *__restrict__ V) {
+    const long i = blockIdx.x * 256L + threadIdx.x;
+    const int h = (int)(i & 1);
+    const long tile = i >> 1;
+    if (tile >= Mt_pad) return;
+    const int KB = C / 8;
+    const int kb0 = blockIdx.y * kb_per_chunk, kb1 = min(KB, kb0 + kb_per_chunk);
+    const bool live = tile < Mt;
+    const int tpi = TH * TW;
+    const int b = live ? (int)(tile / tpi) : 0;
+    const int r = live ? (int)(tile - (long)b * tpi) : 0;
+    const int ty = r / TW, tx = r - ty * TW;
+    const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
+    bool ok[4][4];
+#pragma unroll
+    for (int yy = 0; yy < 4; ++yy)
+#pragma unroll
+        for (int xx = 0; xx < 4; ++xx)
+            ok[yy][xx] = live && (unsigned)(y0 + yy) < (unsigned)H && (unsigned)(x0 + xx) < (unsigned)W;
+    const float *xb = x + (long)b * x_bs + ((long)y0 * W + x0) * C + 4 * h;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (int kb = kb0; kb < kb1; ++kb) {
+        f32x4 d[4][4];
+#pragma unroll
+        for (int yy = 0; yy < 4; ++yy)
+#pragma unroll
+            for (int xx = 0; xx < 4; ++xx) {
+                f32x4 v = zero;
+                if (ok[yy][xx]) v = *reinterpret_cast<const f32x4 *>(xb + ((long)yy * W + xx) * C + 8 * kb);
+                if (relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                d[yy][xx] = v;
+            }
+        f32x4 t[4][4];                                       // B^T d
+#pragma unroll
+        for (int xx = 0; xx < 4; ++xx) {
+            t[0][xx] = d[0][xx] - d[2][xx];
+            t[1][xx] = d[1][xx] + d[2][xx];
+            t[2][xx] = d[2][xx] - d[1][xx];
+            t[3][xx] = d[1][xx] - d[3][xx];
+        }
+#pragma unroll
+        for (int yy = 0; yy < 4; ++yy) {                     // (B^T d) B
+            const f32x4 v0 = t[yy][0] - t[yy][2], v1 = t[yy][1] + t[yy][2], v2 = t[yy][2] - t[yy][1], v3 = t[yy][1] - t[yy][3];
+            float *dst = V + ((((long)(yy * 4) * KB + kb) * Mt_pad + tile) << 3) + 4 * h;
+            const long ps = ((long)KB * Mt_pad) << 3;        // floats between positions
+            *reinterpret_cast<f32x4 *>(dst) = v0;
+            *reinterpret_cast<f32x4 *>(dst + ps) = v1;
+            *reinterpret_cast<f32x4 *>(dst + 2 * ps) = v2;
+            *reinterpret_cast<f32x4 *>(dst + 3 * ps) = v3;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ batched GEMM + output transform
+struct WinoG {
+    const float *V, *U;
+    unsigned v_bytes, u_bytes;
+    int Mt, Mt_pad, KB, N;
+    int TH, TW, OH, OW, B, M;
+    const float *bias, *res;
+    long res_bs; int res_bmod;
+    float *y; long y_bs;
+    int relu_out;
+    int splitk, kb_per_split;
+    float *partial;
+};
+
+__global__ __launch_bounds__(512) void wino_gemm_kernel(const WinoG p, const int tiles_n, const int ntile) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];          // epilogue: [16][64][32]
+    const int nblk = gridDim.x;
+    auto xcd_contiguous = [](int bid, int nb) {
+        const int q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7;
+        return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    };
+    const int swz = xcd_contiguous(blockIdx.x, nblk);
+    const int split = swz / ntile, tile = swz - split * ntile;
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, h = lane >> 5;
+    const int pos0 = 2 * wave;
+    const int kb0 = split * p.kb_per_split, kb1 = min(p.KB, kb0 + p.kb_per_split);
+    const int nk = kb1 - kb0;
+
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.V), 0, p.v_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.U), 0, p.u_bytes, 0x00020000);
+    unsigned va[2][2], vb[2][2];
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi) {
+            va[pi][bi] = (unsigned)((((pos0 + pi) * p.KB + kb0) * (long)p.Mt_pad + tm * WT + 32 * bi + l31) * 32 + h * 16);
+            vb[pi][bi] = (unsigned)((((pos0 + pi) * p.KB + kb0) * (long)p.N + tn * WN + 32 * bi + l31) * 32 + h * 16);
+        }
+    const unsigned sa = (unsigned)p.Mt_pad * 32u, sb = (unsigned)p.N * 32u;   // bytes per k-block
+
+    f32x16 acc[2][2][2];
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+            for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[pi][bi][bj][e] = 0.f;
+
+    auto load = [&](int k, f32x4 (&fa)[2][2], f32x4 (&fb)[2][2]) {
+        const unsigned oa = (unsigned)k * sa, ob = (unsigned)k * sb;
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+            for (int bi = 0; bi < 2; ++bi) {
+                fa[pi][bi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rv, va[pi][bi], oa, 0));
+                fb[pi][bi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ru, vb[pi][bi], ob, 0));
+            }
+    };
+    auto compute = [&](const f32x4 (&fa)[2][2], const f32x4 (&fb)[2][2]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+                for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+                    for (int bj = 0; bj < 2; ++bj)
+                        acc[pi][bi][bj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[pi][bi][j], fb[pi][bj][j], acc[pi][bi][bj], 0, 0, 0);
+    };
+    if (nk > 0) {
+        f32x4 fa0[2][2], fb0[2][2], fa1[2][2], fb1[2][2];
+        load(0, fa0, fb0);
+        int k = 0;
+        // sched_barrier pins "all 8 loads of the next k-block, THEN the 32 MFMAs of this one": left alone hipcc sinks most of
+        // the loads to the end of the MFMA block, right in front of their first use
+        for (; k + 1 < nk; k += 2) {
+            load(k + 1, fa1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(fa0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            load(min(k + 2, nk - 1), fa0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(fa1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (k < nk) compute(fa0, fb0);
+    }
+
+    // ---- epilogue: 32 output channels at a time through LDS, Y = A^T M A
+    const int n_l = t & 31, tsub = t >> 5;                                  // thread -> (channel, tiles tsub + 16 q)
+    const int tpi = p.TH * p.TW, ohw = p.OH * p.OW;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        __syncthreads();
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+            for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    smem[((pos0 + pi) * WT + 32 * bi + (r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l31] = acc[pi][bi][c][r];
+        __syncthreads();
+        const int n = tn * WN + 32 * c + n_l;
+        const float bv = (p.bias && p.splitk == 1) ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int tl = tsub + 16 * q;
+            const long gt = (long)tm * WT + tl;
+            float m[16];
+#pragma unroll
+            for (int ps = 0; ps < 16; ++ps) m[ps] = smem[(ps * WT + tl) * 32 + n_l];
+            if (gt >= p.Mt) continue;
+            // rows of M are the vertical index xi: pos = 4 xi + nu
+            float u0[4], u1[4];
+#pragma unroll
+            for (int nu = 0; nu < 4; ++nu) {
+                u0[nu] = m[nu] + m[4 + nu] + m[8 + nu];
+                u1[nu] = m[4 + nu] - m[8 + nu] - m[12 + nu];
+            }
+            const float yv[2][2] = {{u0[0] + u0[1] + u0[2], u0[1] - u0[2] - u0[3]}, {u1[0] + u1[1] + u1[2], u1[1] - u1[2] - u1[3]}};
+            const int b = (int)(gt / tpi);
+            const int rr = (int)(gt - (long)b * tpi);
+            const int ty = rr / p.TW, tx = rr - ty * p.TW;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int oh = 2 * ty + i, ow = 2 * tx + j;
+                    if (oh >= p.OH || ow >= p.OW) continue;
+                    const long pix = (long)oh * p.OW + ow;
+                    if (p.splitk > 1) {
+                        p.partial[((long)split * p.M + (long)b * ohw + pix) * p.N + n] = yv[i][j];
+                        continue;
+                    }
+                    float v = yv[i][j] + bv;
+                    const long po = pix * p.N + n;
+                    if (p.res) v += p.res[(long)(p.res_bmod ? b % p.res_bmod : b) * p.res_bs + po];
+                    if (p.relu_out) v = fmaxf(v, 0.f);
+                    p.y[p.y_bs ? (long)b * p.y_bs + po : ((long)b * ohw) * p.N + po] = v;
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+static bool wino_enabled() {
+    static const bool on = [] { const char *e = getenv("STCN_WINOGRAD"); return !e || atoi(e) != 0; }();
+    return on;
+}
+
+// floats of V workspace the Winograd path needs for this conv (0: not eligible)
+size_t wino_workspace_floats(const ConvP &p) {
+    if (!wino_enabled() || !p.wino_u || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.x1 || (p.mode & 1)) return 0;
+    if (p.Cin % 8 || p.Cin < 128 || p.N % WN || p.bs0 == 0) return 0;    // 64-channel layers: the transforms cost more than they save
+    const long Mt = (long)p.B * ((p.OH + 1) / 2) * ((p.OW + 1) / 2);
+    const long Mt_pad = (Mt + WT - 1) / WT * WT;
+    if (16L * p.Cin * Mt_pad * 4 >= (1L << 32)) return 0;                  // 32-bit buffer offsets
+    return (size_t)16 * p.Cin * Mt_pad;
+}
+
+// split-K of the Winograd GEMM: with few (tile, channel) workgroups the input channels are cut so that about one round of
+// CUs is busy; the pieces write transformed partial sums into the slabs of conv_reduce_kernel
+int wino_plan_splitk(const ConvP &p, size_t slab_floats) {
+    const int TH = (p.OH + 1) / 2, TW = (p.OW + 1) / 2;
+    const int Mt_pad = (p.B * TH * TW + WT - 1) / WT * WT, KB = p.Cin / 8;
+    const int ntile = (Mt_pad / WT) * (p.N / WN);
+    int sk = 1;
+    if (ntile < 160) {
+        sk = (256 + ntile - 1) / ntile;
+        const int smax = KB / 8 < 1 ? 1 : KB / 8;        // at least 8 k-blocks per piece
+        sk = sk > smax ? smax : sk;
+        while (sk > 1 && (size_t)sk * p.M * p.N > slab_floats) --sk;
+    }
+    const int per = (KB + sk - 1) / sk;
+    return (KB + per - 1) / per;
+}
+
+// Winograd launch of a conv that wino_workspace_floats() accepted; V >= that many floats.  ev: optional {start, stop} pairs for
+// the transform, GEMM and reduce dispatches.  Returns the split-K factor used.
+void wino_launch(const ConvP &p, float *V, size_t slab_floats, hipStream_t s, hipEvent_t *ev_in, hipEvent_t *ev_gemm, hipEvent_t *ev_red) {
+    const int TH = (p.OH + 1) / 2, TW = (p.OW + 1) / 2;
+    const int Mt = p.B * TH * TW, Mt_pad = (Mt + WT - 1) / WT * WT, KB = p.Cin / 8;
+    // ---- input transform: 2 threads per tile, k-blocks cut into chunks so that the grid fills the chip
+    {
+        const unsigned gx = (unsigned)((2L * Mt_pad + 255) / 256);
+        int chunks = (int)((2048 + gx - 1) / gx);
+        chunks = chunks < 1 ? 1 : (chunks > KB ? KB : chunks);
+        const int per = (KB + chunks - 1) / chunks;
+        chunks = (KB + per - 1) / per;
+        if (ev_in)
+            hipExtLaunchKernelGGL(wino_input_kernel, dim3(gx, chunks), dim3(256), 0, s, ev_in[0], ev_in[1], 0, p.x0, p.bs0, p.H, p.W, p.Cin,
+                                  p.relu_in, TH, TW, Mt, Mt_pad, per, V);
+        else
+            hipLaunchKernelGGL(wino_input_kernel, dim3(gx, chunks), dim3(256), 0, s, p.x0, p.bs0, p.H, p.W, p.Cin, p.relu_in, TH, TW, Mt,
+                               Mt_pad, per, V);
+    }
+    // ---- GEMM
+    WinoG g{};
+    g.V = V; g.U = p.wino_u;
+    g.v_bytes = (unsigned)((size_t)16 * p.Cin * Mt_pad * 4);
+    g.u_bytes = (unsigned)((size_t)16 * p.Cin * p.N * 4);
+    g.Mt = Mt; g.Mt_pad = Mt_pad; g.KB = KB; g.N = p.N;
+    g.TH = TH; g.TW = TW; g.OH = p.OH; g.OW = p.OW; g.B = p.B; g.M = p.M;
+    g.bias = p.bias; g.res = p.res; g.res_bs = p.res_bs; g.res_bmod = p.res_bmod; g.y = p.y; g.y_bs = p.y_bs; g.relu_out = p.relu_out;
+    const int tiles_m = Mt_pad / WT, tiles_n = p.N / WN, ntile = tiles_m * tiles_n;
+    const int sk = wino_plan_splitk(p, slab_floats);
+    g.kb_per_split = (KB + sk - 1) / sk;
+    g.splitk = sk; g.partial = p.partial;
+    const size_t lds = (size_t)16 * WT * 32 * sizeof(float);
+    allow_big_lds(reinterpret_cast<const void *>(&wino_gemm_kernel), lds);
+    if (ev_gemm)
+        hipExtLaunchKernelGGL(wino_gemm_kernel, dim3(ntile * sk), dim3(512), lds, s, ev_gemm[0], ev_gemm[1], 0, g, tiles_n, ntile);
+    else
+        hipLaunchKernelGGL(wino_gemm_kernel, dim3(ntile * sk), dim3(512), lds, s, g, tiles_n, ntile);
+    if (sk > 1) {
+        ConvP q = p;
+        q.splitk = sk;
+        conv_reduce_launch(q, s, ev_red);
+    }
+}
+
+// U [16][Cin/8][N][8] from the BN-folded direct weights w [N][Kp] (k = (ky*3 + kx) * Cin + c), on the host in double
+void wino_transform_weights(const float *w, int N, int Cin, int Kp, float *U) {
+    static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    const int KB = Cin / 8;
+    for (int n = 0; n < N; ++n)
+        for (int c = 0; c < Cin; ++c) {
+            double g[3][3], tmp[4][3];
+            for (int ky = 0; ky < 3; ++ky)
+                for (int kx = 0; kx < 3; ++kx) g[ky][kx] = w[(size_t)n * Kp + (size_t)(ky * 3 + kx) * Cin + c];
+            for (int i = 0; i < 4; ++i)
+                for (int kx = 0; kx < 3; ++kx) tmp[i][kx] = G[i][0] * g[0][kx] + G[i][1] * g[1][kx] + G[i][2] * g[2][kx];
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 4; ++j) {
+                    const double u = tmp[i][0] * G[j][0] + tmp[i][1] * G[j][1] + tmp[i][2] * G[j][2];
+                    U[((((size_t)(i * 4 + j) * KB + c / 8) * N + n) << 3) + (c & 7)] = (float)u;
+                }
+        }
+}
+
+}  // namespace stcn

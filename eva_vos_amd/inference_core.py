@@ -195,11 +195,12 @@ class InferenceCore:
     def kernel_profile(self) -> dict:
         """Per-kernel-class device ms / launches / algorithmic FLOP of the last interact()."""
         n = len(_lib.K_CLASSES)
-        ms, ln, fl, by = (C.c_float * n)(), (C.c_int32 * n)(), (C.c_double * n)(), (C.c_double * n)()
+        ms, ln, fl, by, ex = (C.c_float * n)(), (C.c_int32 * n)(), (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)()
         _lib.check(_lib.lib().stcn_get_kernel_ms(self._engine, ms, ln))
         _lib.check(_lib.lib().stcn_get_kernel_flops(self._engine, fl))
         _lib.check(_lib.lib().stcn_get_kernel_bytes(self._engine, by))
-        out = {c: dict(ms=ms[i], launches=ln[i], flops=fl[i], bytes=by[i]) for i, c in enumerate(_lib.K_CLASSES)}
+        _lib.check(_lib.lib().stcn_get_kernel_exec_flops(self._engine, ex))
+        out = {c: dict(ms=ms[i], launches=ln[i], flops=fl[i], bytes=by[i], exec_flops=ex[i]) for i, c in enumerate(_lib.K_CLASSES)}
         reg = (C.c_double * 4)()
         _lib.check(_lib.lib().stcn_get_conv_regimes(self._engine, reg))
         # conv launches below the machine balance (HBM-bound); a subset of the "conv" totals

@@ -160,13 +160,16 @@ int stcn_bench_conv(void *stream, int B, int H, int W, int Cin, int Cout, int KH
 /* Per-kernel-class time of the last interact() measured with HIP events on the engine stream
  * (enabled by stcn_engine_set_profiling(e,1); adds a few % overhead).  ms[] indexed by STCN_K_*. */
 enum { STCN_K_CONV = 0, STCN_K_CONV_REDUCE, STCN_K_MEMREAD, STCN_K_ELEMWISE, STCN_K_CONV_N1,
-       STCN_K_OTHER, STCN_K_COUNT };
+       STCN_K_OTHER, STCN_K_WINO_INPUT /* Winograd input transform of the 3x3 convs */, STCN_K_COUNT };
 int stcn_engine_set_profiling(stcn_engine *e, int on);
 int stcn_get_kernel_ms(const stcn_engine *e, float *ms /*[STCN_K_COUNT]*/, int32_t *launches /*[STCN_K_COUNT]*/);
 /* Algorithmic FLOP (2 x MAC) issued per kernel class by the last interact(). */
 int stcn_get_kernel_flops(const stcn_engine *e, double *flops /*[STCN_K_COUNT]*/);
 /* Algorithmic HBM bytes (every operand of every launch once; conv class only) of the last interact(). */
 int stcn_get_kernel_bytes(const stcn_engine *e, double *bytes /*[STCN_K_COUNT]*/);
+/* FLOP the matrix cores actually EXECUTED per class (= the algorithmic FLOP except for the convs that ran as Winograd
+ * F(2x2,3x3): 2.25x fewer multiplies than the 2*M*N*K of stcn_get_kernel_flops). */
+int stcn_get_kernel_exec_flops(const stcn_engine *e, double *flops /*[STCN_K_COUNT]*/);
 /* Conv launches of the last interact() whose arithmetic intensity (algorithmic FLOP / algorithmic bytes) lies below the
  * machine balance 157.3 TFLOP/s / 8 TB/s = 19.7 FLOP/B - HBM-bound, e.g. the 1x1 channel expansions of the key encoder.
  * They are part of the STCN_K_CONV totals; out[4] = { FLOP, bytes, device ms (profiling on), launches }. */
