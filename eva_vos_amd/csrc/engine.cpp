@@ -122,7 +122,7 @@ int make_f16_split(Model &m, ConvW &cw, const std::vector<float> &w) {
 
 int make_wino(Model &m, ConvW &cw, const std::vector<float> &w) {
     static const bool on = [] { const char *e = getenv("STCN_WINOGRAD"); return !e || atoi(e) != 0; }();
-    if (!on || cw.kh != 3 || cw.kw != 3 || cw.cin_p % 8 || cw.cin_p < 128 || cw.cout % 64 || (m.precision & 1)) return STCN_OK;
+    if (!on || cw.kh != 3 || cw.kw != 3 || cw.cin_p % 32 || cw.cin_p < 128 || cw.cout % 64 || (m.precision & 1)) return STCN_OK;
     std::vector<float> u((size_t)16 * cw.cin_p * cw.cout);
     wino_transform_weights(w.data(), cw.cout, cw.cin_p, cw.Kp, u.data());
     return upload(m, u, &cw.wino_u);

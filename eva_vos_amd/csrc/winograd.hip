@@ -36,16 +36,20 @@ static constexpr int WT = 64;        // tiles per workgroup
 static constexpr int WN = 64;        // output channels per workgroup
 
 // ------------------------------------------------------------------------------------------------ input transform
-// thread = (tile, half h of an 8-channel k-block); loops over the k-blocks of its chunk (blockIdx.y)
+// thread = (tile, 16-byte channel group c16 of a 32-channel block): 8 consecutive lanes read one whole 128-byte line of a
+// pixel, 8 consecutive tiles (64 lanes) share their overlapping pixels through L1; a store instruction of the wave writes,
+// per position, 4 k-blocks x 8 tiles x 32 B = four 256-byte runs of V.  Loops over the 32-channel blocks of its chunk
+// (blockIdx.y).  (First version: thread = (tile, half k-block), 32-byte reads at a 2-pixel stride - every 128-byte line
+// came from L2 four times: 15 % of all kernel time.)
 __global__ __launch_bounds__(256) void wino_input_kernel(const float *__restrict__ x, long x_bs, int H, int W, int C, int relu_in,
-                                                         int TH, int TW, int Mt, int Mt_pad, int kb_per_chunk,
+                                                         int TH, int TW, int Mt, int Mt_pad, int cb_per_chunk,
                                                          float *__restrict__ V) {
     const long i = blockIdx.x * 256L + threadIdx.x;
-    const int h = (int)(i & 1);
-    const long tile = i >> 1;
+    const int c16 = (int)(i & 7);
+    const long tile = i >> 3;
     if (tile >= Mt_pad) return;
-    const int KB = C / 8;
-    const int kb0 = blockIdx.y * kb_per_chunk, kb1 = min(KB, kb0 + kb_per_chunk);
+    const int KB = C / 8, NCB = C / 32;
+    const int cb0 = blockIdx.y * cb_per_chunk, cb1 = min(NCB, cb0 + cb_per_chunk);
     const bool live = tile < Mt;
     const int tpi = TH * TW;
     const int b = live ? (int)(tile / tpi) : 0;
@@ -58,16 +62,17 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float *__restrict
 #pragma unroll
         for (int xx = 0; xx < 4; ++xx)
             ok[yy][xx] = live && (unsigned)(y0 + yy) < (unsigned)H && (unsigned)(x0 + xx) < (unsigned)W;
-    const float *xb = x + (long)b * x_bs + ((long)y0 * W + x0) * C + 4 * h;
+    const float *xb = x + (long)b * x_bs + ((long)y0 * W + x0) * C + 4 * c16;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    for (int kb = kb0; kb < kb1; ++kb) {
+    const long ps = ((long)KB * Mt_pad) << 3;                // floats between positions
+    for (int cb = cb0; cb < cb1; ++cb) {
         f32x4 d[4][4];
 #pragma unroll
         for (int yy = 0; yy < 4; ++yy)
 #pragma unroll
             for (int xx = 0; xx < 4; ++xx) {
                 f32x4 v = zero;
-                if (ok[yy][xx]) v = *reinterpret_cast<const f32x4 *>(xb + ((long)yy * W + xx) * C + 8 * kb);
+                if (ok[yy][xx]) v = *reinterpret_cast<const f32x4 *>(xb + ((long)yy * W + xx) * C + 32 * cb);
                 if (relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 d[yy][xx] = v;
             }
@@ -79,11 +84,12 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float *__restrict
             t[2][xx] = d[2][xx] - d[1][xx];
             t[3][xx] = d[1][xx] - d[3][xx];
         }
+        const int kb = cb * 4 + (c16 >> 1);
+        float *base = V + (((long)kb * Mt_pad + tile) << 3) + 4 * (c16 & 1);
 #pragma unroll
         for (int yy = 0; yy < 4; ++yy) {                     // (B^T d) B
             const f32x4 v0 = t[yy][0] - t[yy][2], v1 = t[yy][1] + t[yy][2], v2 = t[yy][2] - t[yy][1], v3 = t[yy][1] - t[yy][3];
-            float *dst = V + ((((long)(yy * 4) * KB + kb) * Mt_pad + tile) << 3) + 4 * h;
-            const long ps = ((long)KB * Mt_pad) << 3;        // floats between positions
+            float *dst = base + (long)(yy * 4) * ps;
             *reinterpret_cast<f32x4 *>(dst) = v0;
             *reinterpret_cast<f32x4 *>(dst + ps) = v1;
             *reinterpret_cast<f32x4 *>(dst + 2 * ps) = v2;
@@ -165,27 +171,44 @@ __global__ __launch_bounds__(512) void wino_gemm_kernel(const WinoG p, const int
                         acc[pi][bi][bj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[pi][bi][j], fb[pi][bj][j], acc[pi][bi][bj], 0, 0, 0);
     };
     if (nk > 0) {
-        f32x4 fa0[2][2], fb0[2][2], fa1[2][2], fb1[2][2];
+        // three fragment sets: the loads of k-block k+2 are issued before the MFMAs of k-block k, so a fragment has two
+        // blocks (2 x 32 MFMAs x 2 waves per SIMD ~ 3.5 us) to arrive - V streams from HBM at the big layers.
+        // sched_barrier pins "all 8 loads, THEN the 32 MFMAs": left alone hipcc sinks most loads to the end of the MFMA
+        // block, right in front of their first use
+        f32x4 fa0[2][2], fb0[2][2], fa1[2][2], fb1[2][2], fa2[2][2], fb2[2][2];
         load(0, fa0, fb0);
+        load(min(1, nk - 1), fa1, fb1);
         int k = 0;
-        // sched_barrier pins "all 8 loads of the next k-block, THEN the 32 MFMAs of this one": left alone hipcc sinks most of
-        // the loads to the end of the MFMA block, right in front of their first use
-        for (; k + 1 < nk; k += 2) {
-            load(k + 1, fa1, fb1);
+        for (; k + 2 < nk; k += 3) {
+            load(k + 2, fa2, fb2);
             __builtin_amdgcn_sched_barrier(0);
             compute(fa0, fb0);
             __builtin_amdgcn_sched_barrier(0);
-            load(min(k + 2, nk - 1), fa0, fb0);
+            load(min(k + 3, nk - 1), fa0, fb0);
             __builtin_amdgcn_sched_barrier(0);
             compute(fa1, fb1);
             __builtin_amdgcn_sched_barrier(0);
+            load(min(k + 4, nk - 1), fa1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(fa2, fb2);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (k < nk) compute(fa0, fb0);
+        if (k + 1 < nk) compute(fa1, fb1);
     }
 
     // ---- epilogue: 32 output channels at a time through LDS, Y = A^T M A
     const int n_l = t & 31, tsub = t >> 5;                                  // thread -> (channel, tiles tsub + 16 q)
     const int tpi = p.TH * p.TW, ohw = p.OH * p.OW;
+    int tb[4], toh[4], tow[4];                                              // batch element and first output pixel of the 4 tiles
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const long gt = (long)tm * WT + tsub + 16 * q;
+        const int b = gt < p.Mt ? (int)(gt / tpi) : -1;
+        const int rr = (int)(gt - (long)(b < 0 ? 0 : b) * tpi);
+        const int ty = rr / p.TW;
+        tb[q] = b; toh[q] = 2 * ty; tow[q] = 2 * (rr - ty * p.TW);
+    }
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         __syncthreads();
@@ -202,11 +225,11 @@ __global__ __launch_bounds__(512) void wino_gemm_kernel(const WinoG p, const int
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int tl = tsub + 16 * q;
-            const long gt = (long)tm * WT + tl;
             float m[16];
 #pragma unroll
             for (int ps = 0; ps < 16; ++ps) m[ps] = smem[(ps * WT + tl) * 32 + n_l];
-            if (gt >= p.Mt) continue;
+            const int b = tb[q];
+            if (b < 0) continue;
             // rows of M are the vertical index xi: pos = 4 xi + nu
             float u0[4], u1[4];
 #pragma unroll
@@ -215,25 +238,23 @@ __global__ __launch_bounds__(512) void wino_gemm_kernel(const WinoG p, const int
                 u1[nu] = m[4 + nu] - m[8 + nu] - m[12 + nu];
             }
             const float yv[2][2] = {{u0[0] + u0[1] + u0[2], u0[1] - u0[2] - u0[3]}, {u1[0] + u1[1] + u1[2], u1[1] - u1[2] - u1[3]}};
-            const int b = (int)(gt / tpi);
-            const int rr = (int)(gt - (long)b * tpi);
-            const int ty = rr / p.TW, tx = rr - ty * p.TW;
+            const float *resb = p.res ? p.res + (long)(p.res_bmod ? b % p.res_bmod : b) * p.res_bs + n : nullptr;
+            float *yb = p.splitk > 1 ? p.partial + ((long)split * p.M + (long)b * ohw) * p.N + n
+                                     : p.y + (p.y_bs ? (long)b * p.y_bs : (long)b * ohw * p.N) + n;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const int oh = 2 * ty + i, ow = 2 * tx + j;
+                    const int oh = toh[q] + i, ow = tow[q] + j;
                     if (oh >= p.OH || ow >= p.OW) continue;
-                    const long pix = (long)oh * p.OW + ow;
-                    if (p.splitk > 1) {
-                        p.partial[((long)split * p.M + (long)b * ohw + pix) * p.N + n] = yv[i][j];
-                        continue;
+                    const long po = ((long)oh * p.OW + ow) * p.N;
+                    float v = yv[i][j];
+                    if (p.splitk == 1) {
+                        v += bv;
+                        if (resb) v += resb[po];
+                        if (p.relu_out) v = fmaxf(v, 0.f);
                     }
-                    float v = yv[i][j] + bv;
-                    const long po = pix * p.N + n;
-                    if (p.res) v += p.res[(long)(p.res_bmod ? b % p.res_bmod : b) * p.res_bs + po];
-                    if (p.relu_out) v = fmaxf(v, 0.f);
-                    p.y[p.y_bs ? (long)b * p.y_bs + po : ((long)b * ohw) * p.N + po] = v;
+                    yb[po] = v;
                 }
         }
     }
@@ -248,7 +269,7 @@ static bool wino_enabled() {
 // floats of V workspace the Winograd path needs for this conv (0: not eligible)
 size_t wino_workspace_floats(const ConvP &p) {
     if (!wino_enabled() || !p.wino_u || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.x1 || (p.mode & 1)) return 0;
-    if (p.Cin % 8 || p.Cin < 128 || p.N % WN || p.bs0 == 0) return 0;    // 64-channel layers: the transforms cost more than they save
+    if (p.Cin % 32 || p.Cin < 128 || p.N % WN || p.bs0 == 0) return 0;    // 64-channel layers: the transforms cost more than they save
     const long Mt = (long)p.B * ((p.OH + 1) / 2) * ((p.OW + 1) / 2);
     const long Mt_pad = (Mt + WT - 1) / WT * WT;
     if (16L * p.Cin * Mt_pad * 4 >= (1L << 32)) return 0;                  // 32-bit buffer offsets
@@ -277,13 +298,14 @@ int wino_plan_splitk(const ConvP &p, size_t slab_floats) {
 void wino_launch(const ConvP &p, float *V, size_t slab_floats, hipStream_t s, hipEvent_t *ev_in, hipEvent_t *ev_gemm, hipEvent_t *ev_red) {
     const int TH = (p.OH + 1) / 2, TW = (p.OW + 1) / 2;
     const int Mt = p.B * TH * TW, Mt_pad = (Mt + WT - 1) / WT * WT, KB = p.Cin / 8;
-    // ---- input transform: 2 threads per tile, k-blocks cut into chunks so that the grid fills the chip
+    // ---- input transform: 8 threads per tile, the 32-channel blocks cut into chunks so that the grid fills the chip
     {
-        const unsigned gx = (unsigned)((2L * Mt_pad + 255) / 256);
+        const unsigned gx = (unsigned)((8L * Mt_pad + 255) / 256);
+        const int NCB = p.Cin / 32;
         int chunks = (int)((2048 + gx - 1) / gx);
-        chunks = chunks < 1 ? 1 : (chunks > KB ? KB : chunks);
-        const int per = (KB + chunks - 1) / chunks;
-        chunks = (KB + per - 1) / per;
+        chunks = chunks < 1 ? 1 : (chunks > NCB ? NCB : chunks);
+        const int per = (NCB + chunks - 1) / chunks;
+        chunks = (NCB + per - 1) / per;
         if (ev_in)
             hipExtLaunchKernelGGL(wino_input_kernel, dim3(gx, chunks), dim3(256), 0, s, ev_in[0], ev_in[1], 0, p.x0, p.bs0, p.H, p.W, p.Cin,
                                   p.relu_in, TH, TW, Mt, Mt_pad, per, V);

@@ -204,7 +204,7 @@ class InferenceCore:
         reg = (C.c_double * 4)()
         _lib.check(_lib.lib().stcn_get_conv_regimes(self._engine, reg))
         # conv launches below the machine balance (HBM-bound); a subset of the "conv" totals
-        out["conv_hbm_bound"] = dict(ms=reg[2], launches=int(reg[3]), flops=reg[0], bytes=reg[1])
+        out["conv_hbm_bound"] = dict(ms=reg[2], launches=int(reg[3]), flops=reg[0], bytes=reg[1], exec_flops=reg[0])
         return out
 
     def __deepcopy__(self, memo):
