@@ -541,10 +541,11 @@ def main():
                                            "what": "conv launches under 19.7 FLOP/B of algorithmic intensity (1x1 channel expansions, stems)"}}
             # HBM-side bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate runs)
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+                pmc_file = [f for f in ("r02_pmc_traffic.json", "r01_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
+                pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
                 out["roofline"]["traffic"] = pmc["conv_gemm_traffic_bytes_per_launch"]
-                out["roofline"]["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc passes of this workload at T=30)"
-            except OSError:
+                out["roofline"]["traffic_source"] = f"profiles/{pmc_file} (rocprofv3 --pmc passes of this workload at T=30: FETCH_SIZE x2 + WRITE_SIZE per conv GEMM launch)"
+            except (OSError, IndexError):
                 pass
             out["roofline"]["algorithmic_bytes_per_launch"] = conv["bytes"] / max(conv["launches"], 1)
             out["roofline"]["leg"] = f"{max(1, a.roof_steps)} video(s), 1 stream, HIP events per launch"

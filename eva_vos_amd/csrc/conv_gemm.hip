@@ -119,6 +119,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvP p, const int
         const int m = tm * BM + r0 + 32 * i;
         rvalid[i] = m < p.M;
         const int mm = rvalid[i] ? m : 0;
+        if (p.pointwise) {                             // 1x1 / stride 1 / dense: no (b, oh, ow) decode, two integer divisions saved per row
+            ih0[i] = 0; iw0[i] = 0;
+            roff0[i] = (mm * p.c0 + (SMALLC ? 0 : kc * 4)) * 4;
+            roff1[i] = roff0[i];
+            vmask[i] = rvalid[i] ? 1u : 0u;
+            continue;
+        }
         const int b = mm / ohw, pix = mm - b * ohw;
         const int oh = pix / p.OW, ow = pix - oh * p.OW;
         ih0[i] = oh * p.stride - p.pad;
@@ -340,6 +347,23 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvP p, const int
                 continue;
             }
             const float bv = p.bias ? p.bias[n] : 0.f;
+            if (p.affine_out) {
+                // dense [M][N] output (and residual): buffer stores / loads, one address add per row; rows beyond M are dropped
+                // by the hardware range check of the vector offset (first version: ~8 address / predicate VALU ops per row,
+                // which the fp32 MFMA of the co-resident workgroups cannot hide)
+                const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (unsigned)((long)p.M * p.N * 4), 0x00020000);
+                const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.res ? p.res : p.y), 0, (unsigned)((long)p.M * p.N * 4), 0x00020000);
+                const unsigned v0 = (unsigned)(((long)mbase * p.N + n) * 4), n4 = (unsigned)p.N * 4u;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned vo = mbase < p.M ? v0 + (unsigned)((r & 3) + 8 * (r >> 2)) * n4 : OOB;
+                    float v = c[r] + bv;
+                    if (p.res) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, vo, 0, 0));
+                    if (p.relu_out) v = fmaxf(v, 0.f);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, vo, 0, 0);
+                }
+                continue;
+            }
             const bool needb = p.res != nullptr || p.y_bs != 0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {

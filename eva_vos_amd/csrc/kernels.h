@@ -37,6 +37,8 @@ struct ConvP {
     // ([(tile - rem_full) * rem_split + piece][BM][BN]) and are summed by conv_reduce_tiles_kernel
     int rem_full, rem_split, rem_per;
     const float *wino_u;    // Winograd-transformed weights [16][Cin/8][N][8] (stride-1 3x3 convs with Cin >= 64, N % 64 == 0) or nullptr
+    int pointwise;          // 1x1, stride 1, no padding, one dense source: im2col row m IS activation row m (no row decode)
+    int affine_out;         // y (and res, if any) are dense [M][N]: element (m, n) at (m * N + n) * 4 bytes, < 4 GiB
     int tile_big;           // 1 = 128x128 workgroup tiles (fp32 kernel)
     int panel;              // > 0: tiles are walked in panels of this many n-tiles (fp32 kernel)
 };

@@ -188,7 +188,8 @@ __global__ __launch_bounds__(256, 2) void affinity_tile_kernel(
     auto gload = [&](int h) {                                                   // step h (may lie beyond the bank: zeros)
         const unsigned vk = voff_k + (unsigned)h * (HROWS * 256u), vm = voff_m + (unsigned)h * (HROWS * 4u);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) st[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rk, vk, i * 4096, 0));
+        for (int i = 0; i < 4; ++i)      // the chunk offset rides in the VECTOR offset: only that one is range-checked by the hardware
+            st[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rk, vk + i * 4096u, 0, 0));
         stm = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm, vm, 0, 0));
     };
     auto sstore = [&](float *kt) {
