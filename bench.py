@@ -183,7 +183,9 @@ def memread_roofline(k, hw16=1620):
 
 def real_inputs(a):
     """Checkpoints + the first DAVIS-17 val sample, or None when the box does not hold them (the usual case: no network)."""
-    wdir, root = os.path.join(ROOT, "model_weights", "mivos"), os.path.join(ROOT, "data", "DAVIS_17", "trainval")
+    # STCN_BENCH_WEIGHTS / STCN_BENCH_DAVIS relocate the two directories (tests point them at a synthetic tree)
+    wdir = os.environ.get("STCN_BENCH_WEIGHTS", os.path.join(ROOT, "model_weights", "mivos"))
+    root = os.environ.get("STCN_BENCH_DAVIS", os.path.join(ROOT, "data", "DAVIS_17", "trainval"))
     imset = os.path.join(root, "ImageSets", "2017", "val.txt")
     paths = [os.path.join(wdir, "stcn.pth"), os.path.join(wdir, "fusion.pth"), imset]
     if not all(os.path.exists(q) for q in paths):

@@ -500,6 +500,33 @@ __global__ __launch_bounds__(256) void merge_readout_kernel(const float *__restr
     }
 }
 
+// k > 1: the gather of merge_readout_kernel, one wave per (query, OBJECT) instead of one per query looping over the objects
+// (5x the waves in flight for the 50 x 2 KB random rows per query and object; the merge kernel then only selects and
+// softmaxes and leaves idx / weights [Q][50] in scratch)
+__global__ __launch_bounds__(256) void gather_readout_kernel(const int32_t *__restrict__ idx, const float *__restrict__ w, int Q,
+                                                             const float *__restrict__ mv, long mv_os, float *__restrict__ readout,
+                                                             long ro_os) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= Q) return;
+    const float *mvo = mv + (long)blockIdx.y * mv_os;
+    const int myi = lane < TOPK ? idx[(long)q * TOPK + lane] : 0;
+    const float myw = lane < TOPK ? w[(long)q * TOPK + lane] : 0.f;
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 10
+    for (int j = 0; j < TOPK; ++j) {
+        const float wj = __shfl(myw, j);
+        const float *row = mvo + (long)__shfl(myi, j) * 512 + 4 * lane;
+        const f32x4 r0 = *reinterpret_cast<const f32x4 *>(row);
+        const f32x4 r1 = *reinterpret_cast<const f32x4 *>(row + 256);
+        a0 += r0 * wj;
+        a1 += r1 * wj;
+    }
+    float *dst = readout + (long)blockIdx.y * ro_os + (long)q * 512 + 4 * lane;
+    *reinterpret_cast<f32x4 *>(dst) = a0;
+    *reinterpret_cast<f32x4 *>(dst + 256) = a1;
+}
+
 MemReadPlan memread_plan(int N, int Q) {
     MemReadPlan p;
     p.steps = (N + HROWS - 1) / HROWS;
@@ -537,8 +564,18 @@ void memory_read_launch(const float *mk, const float *msq, const float *qk, int 
     hipLaunchKernelGGL(threshold_kernel, dim3((Q + 3) / 4), dim3(256), 0, s, scr.gmax, pl.nc1 * NGRP2, Q, scr.tau);
     hipLaunchKernelGGL((affinity_tile_kernel<true>), dim3(qblocks, pl.nc2), dim3(256), lds2, s, mk, msq, qk, N, Q, pl.steps, 1,
                        pl.spc2, (float *)nullptr, scr.tau, scr.cand_v, scr.cand_i, scr.cand_n);
+    if (k == 1 || topk_idx || topk_w) {
+        hipLaunchKernelGGL(merge_readout_kernel, dim3((Q + 3) / 4), dim3(256), 0, s, scr.cand_v, scr.cand_i, scr.cand_n, pl.nc2, Q,
+                           mv, mv_os, k, readout, ro_os, topk_idx, topk_w);
+        return;
+    }
+    // several objects: merge once per query (indices / weights into the group-maxima scratch, free since threshold_kernel),
+    // then gather with one wave per (query, object)
+    int32_t *gi = reinterpret_cast<int32_t *>(scr.gmax);
+    float *gw = scr.gmax + (size_t)Q * TOPK;
     hipLaunchKernelGGL(merge_readout_kernel, dim3((Q + 3) / 4), dim3(256), 0, s, scr.cand_v, scr.cand_i, scr.cand_n, pl.nc2, Q,
-                       mv, mv_os, k, readout, ro_os, topk_idx, topk_w);
+                       mv, mv_os, 0, readout, ro_os, gi, gw);
+    hipLaunchKernelGGL(gather_readout_kernel, dim3((Q + 3) / 4, k), dim3(256), 0, s, gi, gw, Q, mv, mv_os, readout, ro_os);
 }
 
 void merge_only_launch(const float *cand_v, const int32_t *cand_i, int NC, int Q, const float *mv, long mv_os, int k,

@@ -45,3 +45,27 @@ def test_gpus_flag_launches_that_many_ranks():
     assert abs(frames - 2 * 2 * 11) < 1e-6 * frames + 1e-3
     assert two["cpu_baseline"] is None and "rank 0 at N=1" in two["cpu_baseline_note"]
     assert two["concurrent_videos_bit_identical"]
+
+
+def test_real_data_hook_is_taken_when_checkpoints_and_clips_exist(tmp_path):
+    """eval_annotation_method.py:51-64 loads ./model_weights/mivos/{stcn,fusion}.pth and ./data/DAVIS_17: when both exist
+    bench.py measures on real clips and says so.  Here: the recipe weights saved as checkpoints + a synthetic tree in the
+    DAVIS layout stand in for them (there is no network for the real ones)."""
+    import torch
+    from eva_vos_amd import fq_driver, synth
+    from eva_vos_amd.params import FusionNet, PropagationNetwork
+    wdir = tmp_path / "weights"
+    wdir.mkdir()
+    torch.save(synth.recipe_state_dict(PropagationNetwork()), wdir / "stcn.pth")
+    torch.save(synth.recipe_state_dict(FusionNet()), wdir / "fusion.pth")
+    root = tmp_path / "trainval"
+    imset = fq_driver.make_synthetic_tree(str(root), {"bear": (9, 240, 432, 1)})
+    os.makedirs(root / "ImageSets" / "2017", exist_ok=True)
+    os.replace(imset, root / "ImageSets" / "2017" / "val.txt")
+    env = {"STCN_BENCH_WEIGHTS": str(wdir), "STCN_BENCH_DAVIS": str(root)}
+    flags = [a for a in SMALL if a not in ("--frames", "12", "--height", "240", "--width", "432")]
+    real = run_bench(["--gpus", "1"] + flags, env)
+    assert real["data"] == "real" and "bear__1" in real["config"]["workload"] and "stcn.pth" in real["config"]["weights"]
+    assert real["config"]["frames_per_step"] == 8 and real["value"] > 0
+    synth_line = run_bench(["--gpus", "1", "--data", "synthetic"] + SMALL, env)
+    assert synth_line["data"] == "synthetic"
