@@ -28,6 +28,11 @@ CONVS = [
     (2, 67, 65, 64, 256, 3, 1, 3, 0),       # 548 tiles = 512 + 36 x 4 pieces; ragged last tile, batch 2, residual, relus
     (1, 184, 192, 64, 32, 3, 1, 2, 0),      # narrow tiles: 276 = 256 + 20 x 4 pieces
     (1, 368, 400, 8, 64, 7, 2, 2, 0),       # generic-path stem: 575 = 512 + 63 x 3 pieces
+    # Winograd F(2x2,3x3) path (stride-1 3x3, Cin >= 128, Cout % 64 == 0): odd sizes (ragged last tile row / column, padded
+    # tile count), batch 2 with residual and both ReLUs, split over input channels when few tiles
+    (2, 17, 23, 128, 128, 3, 1, 3, 0),
+    (1, 31, 45, 256, 64, 3, 1, 0, 0),
+    (3, 16, 20, 512, 192, 3, 1, 2, 0),
 ]
 
 

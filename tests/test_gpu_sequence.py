@@ -414,3 +414,16 @@ def test_new_weights_in_the_same_module_are_picked_up(weights):
     d = make_core((p, f))(img, 1, 2)
     d.interact(msk[:, 0], 0)
     assert torch.equal(d.prob, pa)
+
+
+def test_the_3x3_convs_really_run_as_winograd(nets):
+    """Guards against a silent fall-back to the direct kernel: at 480p the profile must show Winograd input transforms and
+    fewer EXECUTED than algorithmic conv FLOP (85 % of the conv FLOP are stride-1 3x3 convs with >= 128 channels)."""
+    T, H, W = 4, 480, 854
+    core = make_core(nets)(synth.synthetic_clip(T, H, W), 1, 2)
+    core.set_profiling(True)
+    core.interact(synth.synthetic_mask(T, H, W, 1)[:, 0], 0)
+    prof = core.kernel_profile()
+    assert prof["wino_input"]["launches"] > 0 and prof["wino_input"]["ms"] > 0
+    ratio = prof["conv"]["exec_flops"] / prof["conv"]["flops"]
+    assert 0.45 < ratio < 0.65, ratio          # 1 / 2.25 on the Winograd share, 1 on the rest, + tile padding
