@@ -427,3 +427,28 @@ def test_the_3x3_convs_really_run_as_winograd(nets):
     assert prof["wino_input"]["launches"] > 0 and prof["wino_input"]["ms"] > 0
     ratio = prof["conv"]["exec_flops"] / prof["conv"]["flops"]
     assert 0.45 < ratio < 0.65, ratio          # 1 / 2.25 on the Winograd share, 1 on the rest, + tile padding
+
+
+def test_multi_object_decode_groups_equal_the_frame_by_frame_path(nets, monkeypatch):
+    """k = 3, mem_freq = 5: the frames between two bank insertions are decoded as ONE batch of objects x frames (per-frame
+    tensors broadcast over the objects by a modulo batch index).  Same engine with STCN_DECODE_BATCH=1 (the reference's
+    loop order, prop_net.py:183-187 / inference_core.py:166-188) must give the same masks and, up to fp32 summation order of
+    differently shaped GEMMs, the same probabilities."""
+    T, H, W, k = 12, 128, 160, 3
+    img, msk = synth.synthetic_clip(T, H, W, seed=3), synth.synthetic_mask(T, H, W, k, seed=4)
+    m0 = torch.cat([1 - msk[:, 0].sum(0, keepdim=True).clamp(0, 1), msk[:, 0]], 0)
+    m7 = torch.cat([1 - msk[:, 7].sum(0, keepdim=True).clamp(0, 1), msk[:, 7]], 0)
+    outs = []
+    for batch in ("1", None):
+        if batch:
+            monkeypatch.setenv("STCN_DECODE_BATCH", batch)
+        else:
+            monkeypatch.delenv("STCN_DECODE_BATCH", raising=False)
+        core = make_core(nets)(img, k, 5)
+        a = core.interact(m0, 0, scribble=True).copy()
+        b = core.interact(m7, 7, scribble=True).copy()
+        outs.append((a, b, core.prob.clone()))
+    for o in range(1, k + 1):
+        assert iou(outs[0][0] == o, outs[1][0] == o) >= 1 - 1e-3 and iou(outs[0][1] == o, outs[1][1] == o) >= 1 - 1e-3
+    d = (outs[0][2] - outs[1][2]).abs()
+    assert float(torch.quantile(d.flatten()[::3].float(), 0.999)) < 1e-3, float(d.max())
