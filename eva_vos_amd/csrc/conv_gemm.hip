@@ -48,22 +48,24 @@ static constexpr unsigned OOB = 0x80000000u;    // byte offset beyond any tensor
 // the weight slices in flight shrink to one panel, at the price of fetching the activations once per panel - measured
 // on up_16_8.skip_conv over a 5-frame group with 64x64 tiles: FETCH_SIZE 652 -> 348 MB (panels of 4), 250 MB (of 2);
 // over the whole path -10 % (the heavy shapes run on 128x128 tiles, which already fetch 3.8x less), same speed.
-__device__ __forceinline__ void tile_to_mn(int tile, int tiles_n, int ntile, int pn, int &tm, int &tn) {
+struct TileDiv { FastDiv ntile, tiles_n, per_panel; int tiles_m; };      // invariants of one launch (host: conv_launch)
+__device__ __forceinline__ void tile_to_mn(int tile, int tiles_n, int ntile, int pn, const TileDiv &td, int &tm, int &tn) {
     if (pn > 0 && tiles_n % pn == 0 && tiles_n > pn) {
-        const int tiles_m = ntile / tiles_n, per_panel = tiles_m * pn;
-        const int panel = tile / per_panel, rem = tile - panel * per_panel;
-        tm = rem / pn;
+        const int per_panel = td.tiles_m * pn;
+        const int panel = fastdiv(tile, td.per_panel), rem = tile - panel * per_panel;
+        tm = pn == 4 ? rem >> 2 : rem / pn;
         tn = panel * pn + (rem - tm * pn);
     } else {
-        tm = tile / tiles_n;
+        tm = fastdiv(tile, td.tiles_n);
         tn = tile - tm * tiles_n;
     }
+    (void)ntile;
 }
 
 // WM x WN waves per workgroup, each owning RM x RN accumulator blocks of 32x32: workgroup tile (32 WM RM) x (32 WN RN).
 template <int WM, int WN, int RM, int RN, bool SMALLC, bool RELU>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvP p, const int tiles_n,
-                                                        const int ntile, const int kt_per_split) {
+                                                        const int ntile, const int kt_per_split, const TileDiv td) {
     constexpr int PA = WM * RM, PB = WN * RN;          // 32-row pieces of the A / B tiles (= staging chunks per thread)
     constexpr int BM = 32 * PA, BN = 32 * PB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -92,11 +94,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvP p, const int
         }
     } else {
         const int swz = xcd_contiguous(blockIdx.x, gridDim.x);
-        split = swz / ntile;
+        split = fastdiv(swz, td.ntile);
         tile = swz - split * ntile;
     }
     int tm, tn;
-    tile_to_mn(tile, tiles_n, ntile, p.panel, tm, tn);
+    tile_to_mn(tile, tiles_n, ntile, p.panel, td, tm, tn);
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / WN, wn = wave - wm * WN;
@@ -126,8 +128,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvP p, const int
             vmask[i] = rvalid[i] ? 1u : 0u;
             continue;
         }
-        const int b = mm / ohw, pix = mm - b * ohw;
-        const int oh = pix / p.OW, ow = pix - oh * p.OW;
+        const int b = fastdiv(mm, p.fd_ohw), pix = mm - b * ohw;
+        const int oh = fastdiv(pix, p.fd_ow), ow = pix - oh * p.OW;
         ih0[i] = oh * p.stride - p.pad;
         iw0[i] = ow * p.stride - p.pad;
         roff0[i] = (b * (int)p.bs0 + (ih0[i] * p.W + iw0[i]) * p.c0 + (SMALLC ? 0 : kc * 4)) * 4;
@@ -372,7 +374,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvP p, const int
                     float v = c[r] + bv;
                     long yo = (long)m * p.N + n;
                     if (needb) {
-                        const int b = p.B == 1 ? 0 : m / ohw;
+                        const int b = p.B == 1 ? 0 : fastdiv(m, p.fd_ohw);
                         const long po = (long)(m - b * ohw) * p.N + n;
                         if (p.res) v += p.res[(long)(p.res_bmod ? b % p.res_bmod : b) * p.res_bs + po];
                         if (p.y_bs) yo = (long)b * p.y_bs + po;
@@ -413,13 +415,14 @@ __global__ __launch_bounds__(256) void conv_reduce_kernel(const ConvP p) {
 }
 
 // tail balancing: y(tile) = sum over the K pieces of the tile-local partials + epilogue; one block per 32 tile rows
-__global__ __launch_bounds__(256) void conv_reduce_tiles_kernel(const ConvP p, const int tiles_n, const int ntile, const int BM, const int BN) {
+__global__ __launch_bounds__(256) void conv_reduce_tiles_kernel(const ConvP p, const int tiles_n, const int ntile, const int BM, const int BN,
+                                                                const TileDiv td) {
     const int rows_per_blk = 1024 / BN;                          // 256 threads x 4 columns
     const int blks_per_tile = BM / rows_per_blk;
     const int rt = blockIdx.x / blks_per_tile, rb = blockIdx.x - rt * blks_per_tile;
     const int tile = p.rem_full + rt;
     int tm, tn;
-    tile_to_mn(tile, tiles_n, ntile, p.panel, tm, tn);
+    tile_to_mn(tile, tiles_n, ntile, p.panel, td, tm, tn);
     const int e4 = threadIdx.x * 4;
     const int row = rb * rows_per_blk + e4 / BN, col = e4 - (e4 / BN) * BN;
     const int m = tm * BM + row, n = tn * BN + col;
@@ -535,6 +538,8 @@ void conv_launch(const ConvP &p, hipStream_t s, hipEvent_t *ev_gemm, hipEvent_t 
     const bool tail = p.rem_split > 1;
     const dim3 grid(tail ? p.rem_full + (ntile - p.rem_full) * p.rem_split : ntile * p.splitk);
     const bool smallc = smallc_variant(p);
+    const int pn = p.panel;
+    const TileDiv td{fastdiv_make((unsigned)ntile), fastdiv_make((unsigned)tiles_n), fastdiv_make((unsigned)(tiles_m * (pn > 0 ? pn : 1))), tiles_m};
     hipEvent_t e0 = ev_gemm ? ev_gemm[0] : nullptr, e1 = ev_gemm ? ev_gemm[1] : nullptr;
     if (p.mode & 1) {
         conv_f16x3_launch(p, tiles_n, ntile, per, grid, s, e0, e1);
@@ -543,8 +548,8 @@ void conv_launch(const ConvP &p, hipStream_t s, hipEvent_t *ev_gemm, hipEvent_t 
     do {                                                                                                                 \
         auto kfn = conv_gemm_kernel<WM_, WN_, RM_, RN_, SC_, RL_>;                                                       \
         allow_big_lds(reinterpret_cast<const void *>(kfn), lds);                                                         \
-        if (e0) hipExtLaunchKernelGGL(kfn, grid, dim3(256), lds, s, e0, e1, 0, p, tiles_n, ntile, per);                  \
-        else hipLaunchKernelGGL(kfn, grid, dim3(256), lds, s, p, tiles_n, ntile, per);                                   \
+        if (e0) hipExtLaunchKernelGGL(kfn, grid, dim3(256), lds, s, e0, e1, 0, p, tiles_n, ntile, per, td);              \
+        else hipLaunchKernelGGL(kfn, grid, dim3(256), lds, s, p, tiles_n, ntile, per, td);                               \
     } while (0)
     const int key = (big ? 8 : 0) | (narrow ? 4 : 0) | (smallc ? 2 : 0) | (p.relu_in ? 1 : 0);
     switch (key) {
@@ -564,9 +569,9 @@ void conv_launch(const ConvP &p, hipStream_t s, hipEvent_t *ev_gemm, hipEvent_t 
     if (tail) {
         const unsigned blocks = (unsigned)((ntile - p.rem_full) * (BM * BN / 1024));
         if (ev_red)
-            hipExtLaunchKernelGGL(conv_reduce_tiles_kernel, dim3(blocks), dim3(256), 0, s, ev_red[0], ev_red[1], 0, p, tiles_n, ntile, BM, BN);
+            hipExtLaunchKernelGGL(conv_reduce_tiles_kernel, dim3(blocks), dim3(256), 0, s, ev_red[0], ev_red[1], 0, p, tiles_n, ntile, BM, BN, td);
         else
-            hipLaunchKernelGGL(conv_reduce_tiles_kernel, dim3(blocks), dim3(256), 0, s, p, tiles_n, ntile, BM, BN);
+            hipLaunchKernelGGL(conv_reduce_tiles_kernel, dim3(blocks), dim3(256), 0, s, p, tiles_n, ntile, BM, BN, td);
     } else if (p.splitk > 1) {
         conv_reduce_launch(p, s, ev_red);
     }

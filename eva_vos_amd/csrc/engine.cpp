@@ -357,6 +357,8 @@ int run_conv(const Model &m, Work &w, hipStream_t s, const char *name, const flo
     p.mode = ((m.precision & 1) && cw.w_hi) ? 1 : 0;
     p.bias = cw.bias; p.res = res; p.res_bs = res_bs; p.res_bmod = res_bmod; p.y = y; p.y_bs = y_bs;
     p.relu_in = relu_in; p.relu_out = relu_out;
+    p.fd_ohw = fastdiv_make((unsigned)(p.OH * p.OW));
+    p.fd_ow = fastdiv_make((unsigned)p.OW);
     p.pointwise = cw.kh == 1 && cw.kw == 1 && stride == 1 && !x1 && bs0 == (long)H * W * c0;
     p.affine_out = (y_bs == 0 || y_bs == (long)p.OH * p.OW * p.N) && (!res || (res_bs == (long)p.OH * p.OW * p.N && !res_bmod)) &&
                    ((long)p.M + 64) * p.N * 4 < (1L << 32);

@@ -5,6 +5,29 @@
 
 namespace stcn {
 
+// ---------------------------------------------------------------- division by a launch invariant
+// An integer division by a run-time value costs ~25 VALU instructions on gfx950 (float reciprocal + correction), also for
+// wave-uniform operands; the conv kernels did 5-10 of them per workgroup in set-up / epilogue code, which the fp32 MFMA of the
+// co-resident workgroups cannot hide.  q = (x * magic) >> (31 + s) with magic = floor(2^(31+s) / d) + 1, s = ceil(log2 d), is
+// exact for 0 <= x < 2^31 (x * (magic * d - 2^(31+s)) <= x * d < 2^(31+s)): one v_mul_hi + one shift.
+struct FastDiv {
+    unsigned magic, shift, d;       // shift = s - 1 (after the mul_hi's 32); d == 1: identity
+};
+static inline FastDiv fastdiv_make(unsigned d) {
+    FastDiv f{0, 0, d};
+    if (d <= 1) return f;
+    unsigned s = 0;
+    while ((1ull << s) < d) ++s;
+    f.magic = (unsigned)(((1ull << (31 + s)) / d) + 1);
+    f.shift = s - 1;
+    return f;
+}
+#if defined(__HIPCC__)
+__device__ __forceinline__ int fastdiv(int x, const FastDiv f) {
+    return f.d <= 1 ? x : (int)(__umulhi((unsigned)x, f.magic) >> f.shift);
+}
+#endif
+
 // ---------------------------------------------------------------- implicit-GEMM convolution
 // Activations NHWC fp32.  Input = channel-concat of up to two sources (second may be batch-broadcast).
 struct ConvP {
@@ -37,6 +60,7 @@ struct ConvP {
     // ([(tile - rem_full) * rem_split + piece][BM][BN]) and are summed by conv_reduce_tiles_kernel
     int rem_full, rem_split, rem_per;
     const float *wino_u;    // Winograd-transformed weights [16][Cin/8][N][8] (stride-1 3x3 convs with Cin >= 64, N % 64 == 0) or nullptr
+    FastDiv fd_ohw, fd_ow;  // divisions by OH*OW and OW
     int pointwise;          // 1x1, stride 1, no padding, one dense source: im2col row m IS activation row m (no row decode)
     int affine_out;         // y (and res, if any) are dense [M][N]: element (m, n) at (m * N + n) * 4 bytes, < 4 GiB
     int tile_big;           // 1 = 128x128 workgroup tiles (fp32 kernel)

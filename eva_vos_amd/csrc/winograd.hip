@@ -110,6 +110,7 @@ struct WinoG {
     int relu_out;
     int splitk, kb_per_split;
     float *partial;
+    FastDiv fd_tpi, fd_tw, fd_ntile, fd_tiles_n;
 };
 
 __global__ __launch_bounds__(512) void wino_gemm_kernel(const WinoG p, const int tiles_n, const int ntile) {
@@ -120,8 +121,8 @@ __global__ __launch_bounds__(512) void wino_gemm_kernel(const WinoG p, const int
         return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
     };
     const int swz = xcd_contiguous(blockIdx.x, nblk);
-    const int split = swz / ntile, tile = swz - split * ntile;
-    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int split = fastdiv(swz, p.fd_ntile), tile = swz - split * ntile;
+    const int tm = fastdiv(tile, p.fd_tiles_n), tn = tile - tm * tiles_n;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, h = lane >> 5;
     const int pos0 = 2 * wave;
     const int kb0 = split * p.kb_per_split, kb1 = min(p.KB, kb0 + p.kb_per_split);
@@ -204,9 +205,9 @@ __global__ __launch_bounds__(512) void wino_gemm_kernel(const WinoG p, const int
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const long gt = (long)tm * WT + tsub + 16 * q;
-        const int b = gt < p.Mt ? (int)(gt / tpi) : -1;
+        const int b = gt < p.Mt ? fastdiv((int)gt, p.fd_tpi) : -1;
         const int rr = (int)(gt - (long)(b < 0 ? 0 : b) * tpi);
-        const int ty = rr / p.TW;
+        const int ty = fastdiv(rr, p.fd_tw);
         tb[q] = b; toh[q] = 2 * ty; tow[q] = 2 * (rr - ty * p.TW);
     }
 #pragma unroll
@@ -322,6 +323,8 @@ void wino_launch(const ConvP &p, float *V, size_t slab_floats, hipStream_t s, hi
     g.TH = TH; g.TW = TW; g.OH = p.OH; g.OW = p.OW; g.B = p.B; g.M = p.M;
     g.bias = p.bias; g.res = p.res; g.res_bs = p.res_bs; g.res_bmod = p.res_bmod; g.y = p.y; g.y_bs = p.y_bs; g.relu_out = p.relu_out;
     const int tiles_m = Mt_pad / WT, tiles_n = p.N / WN, ntile = tiles_m * tiles_n;
+    g.fd_tpi = fastdiv_make((unsigned)(TH * TW)); g.fd_tw = fastdiv_make((unsigned)TW);
+    g.fd_ntile = fastdiv_make((unsigned)ntile); g.fd_tiles_n = fastdiv_make((unsigned)tiles_n);
     const int sk = wino_plan_splitk(p, slab_floats);
     g.kb_per_split = (KB + sk - 1) / sk;
     g.splitk = sk; g.partial = p.partial;
