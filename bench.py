@@ -63,8 +63,10 @@ def parse():
     ap.add_argument("--no-profile", action="store_true", help="skip the roofline leg (roofline = null)")
     ap.add_argument("--roof-steps", type=int, default=1, help="videos of the profiled single-stream roofline leg")
     ap.add_argument("--streams", type=int, default=4, help="videos in flight per GPU (one host thread + HIP stream each)")
-    ap.add_argument("--no-f16x3-leg", dest="f16x3_leg", action="store_false",
-                    help="skip the extra (non-headline) f16x3 split-precision leg")
+    ap.add_argument("--f16x3-leg", dest="f16x3_leg", action="store_true", default=False,
+                    help="also run the extra (non-headline) f16x3 split-precision leg (opt-in since round 2: with the 3x3 convs on "
+                         "Winograd the exact-fp32 default is faster than this mode, which still runs direct convs)")
+    ap.add_argument("--no-f16x3-leg", dest="f16x3_leg", action="store_false", help="(default) skip the f16x3 leg")
     ap.add_argument("--no-r2", dest="r2", action="store_false",
                     help="skip the extra R2 number (a second interaction: cached keys + fusion; reported, not the headline)")
     return ap.parse_args()
