@@ -137,15 +137,16 @@ static constexpr int KT_FLOATS = HROWS * 64 + HROWS;                    // key t
 static constexpr int LISTS_PER_WAVE = 2 * 16 * CAP2 + 32;               // LV, LI, CNT, TAU
 static constexpr int NGRP2 = 64;                                        // pass-1 maxima per query per chunk
 
-template <bool COLLECT>
-__global__ __launch_bounds__(256, 2) void affinity_tile_kernel(
+template <bool COLLECT, bool SINGLE = false>
+__global__ __launch_bounds__(256, SINGLE ? 3 : 2) void affinity_tile_kernel(
     const float *__restrict__ mk, const float *__restrict__ msq, const float *__restrict__ qk, int N, int Q, int ns,
     int ss, int spc, float *__restrict__ gmax, const float *__restrict__ tau_in, float *__restrict__ cand_v,
     int32_t *__restrict__ cand_i, int32_t *__restrict__ cand_n) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    float *KT = smem;                                                   // [2][KT_FLOATS]
-    float *LV = smem + 2 * KT_FLOATS + wave * LISTS_PER_WAVE;           // [16][CAP2]      (pass 2 only)
+    constexpr int NBUF = SINGLE ? 1 : 2;                                // SINGLE: one key tile buffer, two barriers per step, 3 workgroups per CU
+    float *KT = smem;                                                   // [NBUF][KT_FLOATS]
+    float *LV = smem + NBUF * KT_FLOATS + wave * LISTS_PER_WAVE;        // [16][CAP2]      (pass 2 only)
     int *LI = reinterpret_cast<int *>(LV + 16 * CAP2);                  // [16][CAP2]
     int *CNT = LI + 16 * CAP2;                                          // [16]
     float *TAU = reinterpret_cast<float *>(CNT + 16);                   // [16]
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void affinity_tile_kernel(
     __syncthreads();
 
     auto step = [&](const int j, auto bufc) {
-        constexpr int BUF = decltype(bufc)::value;
+        constexpr int BUF = SINGLE ? 0 : decltype(bufc)::value;
         const float *kt = KT + BUF * KT_FLOATS;
         const int row0 = j * ss * HROWS;
         // ---- U tile: acc[rb][e] = mk[row] . qk[q] - |mk[row]|^2 / 2, row = row0 + 16 rb + 4 g + e, q = q0 + col
@@ -219,8 +220,10 @@ __global__ __launch_bounds__(256, 2) void affinity_tile_kernel(
         __builtin_amdgcn_sched_barrier(0);
         // tile j+1 (loaded a step ago) -> the buffer whose readers finished before the previous barrier; tile j+2 -> registers
         // (unconditional: past the chunk they move zeros / an unused tile)
-        sstore(KT + (BUF ^ 1) * KT_FLOATS);
-        gload((j + 2) * ss);
+        if (!SINGLE) {
+            sstore(KT + (BUF ^ 1) * KT_FLOATS);
+            gload((j + 2) * ss);
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
@@ -300,6 +303,11 @@ __global__ __launch_bounds__(256, 2) void affinity_tile_kernel(
             }
         }
         __syncthreads();
+        if (SINGLE) {                                                    // every wave is done with the tile: overwrite it
+            sstore(KT);
+            gload((j + 2) * ss);
+            __syncthreads();
+        }
     };
     {
         using B0 = std::integral_constant<int, 0>;
@@ -527,6 +535,13 @@ __global__ __launch_bounds__(256) void gather_readout_kernel(const int32_t *__re
     *reinterpret_cast<f32x4 *>(dst + 256) = a1;
 }
 
+static bool memread_single_buffer() {
+    // pass 2 with ONE key tile buffer: 50 KB of LDS per workgroup = 3 workgroups (12 waves) per CU instead of 2; the third
+    // workgroup hides the second barrier per step and the LDS-atomic latencies of the appends (+3..5 % on large banks)
+    static const bool on = [] { const char *e = getenv("STCN_MEMREAD_SINGLEBUF"); return !e || atoi(e) != 0; }();
+    return on;
+}
+
 MemReadPlan memread_plan(int N, int Q) {
     MemReadPlan p;
     p.steps = (N + HROWS - 1) / HROWS;
@@ -545,7 +560,7 @@ MemReadPlan memread_plan(int N, int Q) {
         return (steps + *spc - 1) / *spc;
     };
     p.nc1 = chunks(p.ns, 1024, MAXCHUNK1, &p.spc1);         // 64 maxima per chunk and query: <= 512 for threshold_kernel
-    p.nc2 = chunks(p.steps, 512, MAXCHUNK2, &p.spc2);
+    p.nc2 = chunks(p.steps, memread_single_buffer() ? 768 : 512, MAXCHUNK2, &p.spc2);
     return p;
 }
 // bound of nc * Q over both passes: nc1 <= min(8, 1024 / qblocks) and nc2 <= max(1, 512 / qblocks) with Q <= 64 qblocks
@@ -557,13 +572,18 @@ void memory_read_launch(const float *mk, const float *msq, const float *qk, int 
     const MemReadPlan pl = memread_plan(N, Q);
     const int qblocks = (Q + 63) / 64;
     const size_t lds1 = (size_t)2 * KT_FLOATS * sizeof(float);
-    const size_t lds2 = lds1 + (size_t)4 * LISTS_PER_WAVE * sizeof(float);
+    const bool single = memread_single_buffer();
+    const size_t lds2 = (single ? lds1 / 2 : lds1) + (size_t)4 * LISTS_PER_WAVE * sizeof(float);
     allow_big_lds(reinterpret_cast<const void *>(&affinity_tile_kernel<true>), lds2);
     hipLaunchKernelGGL((affinity_tile_kernel<false>), dim3(qblocks, pl.nc1), dim3(256), lds1, s, mk, msq, qk, N, Q, pl.ns, pl.ss,
                        pl.spc1, scr.gmax, (const float *)nullptr, (float *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
     hipLaunchKernelGGL(threshold_kernel, dim3((Q + 3) / 4), dim3(256), 0, s, scr.gmax, pl.nc1 * NGRP2, Q, scr.tau);
-    hipLaunchKernelGGL((affinity_tile_kernel<true>), dim3(qblocks, pl.nc2), dim3(256), lds2, s, mk, msq, qk, N, Q, pl.steps, 1,
-                       pl.spc2, (float *)nullptr, scr.tau, scr.cand_v, scr.cand_i, scr.cand_n);
+    if (single)
+        hipLaunchKernelGGL((affinity_tile_kernel<true, true>), dim3(qblocks, pl.nc2), dim3(256), lds2, s, mk, msq, qk, N, Q, pl.steps, 1,
+                           pl.spc2, (float *)nullptr, scr.tau, scr.cand_v, scr.cand_i, scr.cand_n);
+    else
+        hipLaunchKernelGGL((affinity_tile_kernel<true>), dim3(qblocks, pl.nc2), dim3(256), lds2, s, mk, msq, qk, N, Q, pl.steps, 1,
+                           pl.spc2, (float *)nullptr, scr.tau, scr.cand_v, scr.cand_i, scr.cand_n);
     if (k == 1 || topk_idx || topk_w) {
         hipLaunchKernelGGL(merge_readout_kernel, dim3((Q + 3) / 4), dim3(256), 0, s, scr.cand_v, scr.cand_i, scr.cand_n, pl.nc2, Q,
                            mv, mv_os, k, readout, ro_os, topk_idx, topk_w);
