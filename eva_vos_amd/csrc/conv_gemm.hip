@@ -63,7 +63,9 @@ __device__ __forceinline__ void tile_to_mn(int tile, int tiles_n, int ntile, int
 }
 
 // WM x WN waves per workgroup, each owning RM x RN accumulator blocks of 32x32: workgroup tile (32 WM RM) x (32 WN RN).
-template <int WM, int WN, int RM, int RN, bool SMALLC, bool RELU>
+// PW: pointwise instance (1x1, stride 1, one dense source): no tap walk, no validity masks, no row decode - the set-up and
+// per-K-tile scalar code of the general instance is as long as the MFMA work of an 8-K-tile ResNet 1x1 conv.
+template <int WM, int WN, int RM, int RN, bool SMALLC, bool RELU, bool PW = false>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvP p, const int tiles_n,
                                                         const int ntile, const int kt_per_split, const TileDiv td) {
     constexpr int PA = WM * RM, PB = WN * RN;          // 32-row pieces of the A / B tiles (= staging chunks per thread)
@@ -121,6 +123,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvP p, const int
         const int m = tm * BM + r0 + 32 * i;
         rvalid[i] = m < p.M;
         const int mm = rvalid[i] ? m : 0;
+        if (PW) {                                      // the im2col row IS activation row m; invalid rows read out of range (zero)
+            ih0[i] = 0; iw0[i] = 0; vmask[i] = 0;
+            roff0[i] = rvalid[i] ? (mm * p.c0 + kc * 4) * 4 : (int)OOB;
+            roff1[i] = roff0[i];
+            continue;
+        }
         if (p.pointwise) {                             // 1x1 / stride 1 / dense: no (b, oh, ow) decode, two integer divisions saved per row
             ih0[i] = 0; iw0[i] = 0;
             roff0[i] = (mm * p.c0 + (SMALLC ? 0 : kc * 4)) * 4;
@@ -165,7 +173,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvP p, const int
     // Only the visiting order changes: K tile position q -> weight K tile (tap * Cin/32 + channel block).
     const int ncb = p.Cin / BK, ntap = p.KH * p.KW;
     int u_kh, u_kw, u_cb;
-    if (SMALLC) {
+    if (PW) {
+        u_cb = kt0 * BK; u_kh = 0; u_kw = 0;
+    } else if (SMALLC) {
         const int k0 = kt0 * BK;
         const int tap = k0 / p.Cin;
         u_cb = k0 - tap * p.Cin;
@@ -190,7 +200,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvP p, const int
     unsigned g_bit = 0;
     bool g_src1 = false, g_kvalid = true;
     auto g_tap = [&](int kt) {
-        if (SMALLC) {
+        if (PW) {
+            g_coff = u_cb * 4;
+            g_wkt = min(kt, nkt - 1);
+            u_cb += BK;
+        } else if (SMALLC) {
             const int k = kt * BK + kc * 4;
             g_wkt = kt < nkt ? kt : nkt - 1;
             g_kvalid = k < p.K;
@@ -211,7 +225,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvP p, const int
     auto g_a = [&](int i, auto setc) {
         constexpr int ST = decltype(setc)::value;
         unsigned voff;
-        if (SMALLC) {
+        if (PW) {
+            voff = (unsigned)roff0[i] + (unsigned)g_coff;         // out of range stays out of range (offsets < 2 GiB)
+            ra[ST][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, voff, 0, 0));
+        } else if (SMALLC) {
             const bool ok = g_kvalid && rvalid[i] && (unsigned)(ih0[i] + g_kh) < (unsigned)p.H &&
                             (unsigned)(iw0[i] + g_kw) < (unsigned)p.W;
             voff = ok ? (unsigned)(roff0[i] + g_coff) : OOB;
@@ -544,15 +561,18 @@ void conv_launch(const ConvP &p, hipStream_t s, hipEvent_t *ev_gemm, hipEvent_t 
     if (p.mode & 1) {
         conv_f16x3_launch(p, tiles_n, ntile, per, grid, s, e0, e1);
     } else {
-#define STCN_LAUNCH(WM_, WN_, RM_, RN_, SC_, RL_)                                                                       \
+#define STCN_LAUNCH(WM_, WN_, RM_, RN_, SC_, RL_, ...)                                                                  \
     do {                                                                                                                 \
-        auto kfn = conv_gemm_kernel<WM_, WN_, RM_, RN_, SC_, RL_>;                                                       \
+        auto kfn = conv_gemm_kernel<WM_, WN_, RM_, RN_, SC_, RL_, ##__VA_ARGS__>;                                        \
         allow_big_lds(reinterpret_cast<const void *>(kfn), lds);                                                         \
         if (e0) hipExtLaunchKernelGGL(kfn, grid, dim3(256), lds, s, e0, e1, 0, p, tiles_n, ntile, per, td);              \
         else hipLaunchKernelGGL(kfn, grid, dim3(256), lds, s, p, tiles_n, ntile, per, td);                               \
     } while (0)
-    const int key = (big ? 8 : 0) | (narrow ? 4 : 0) | (smallc ? 2 : 0) | (p.relu_in ? 1 : 0);
+    const bool pw = p.pointwise && !big && !narrow && !smallc;
+    const int key = (pw ? 16 : 0) | (big ? 8 : 0) | (narrow ? 4 : 0) | (smallc ? 2 : 0) | (p.relu_in ? 1 : 0);
     switch (key) {
+        case 16: STCN_LAUNCH(2, 2, 1, 1, false, false, true); break;
+        case 17: STCN_LAUNCH(2, 2, 1, 1, false, true, true); break;
         case 0: STCN_LAUNCH(2, 2, 1, 1, false, false); break;
         case 1: STCN_LAUNCH(2, 2, 1, 1, false, true); break;
         case 2: STCN_LAUNCH(2, 2, 1, 1, true, false); break;
