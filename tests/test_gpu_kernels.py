@@ -201,9 +201,9 @@ def test_gpu_j_and_f_equal_the_cpu_metrics_exactly():
 
 @pytest.mark.parametrize("conv_mode", [0, 1])
 def test_kernels_on_two_streams_do_not_perturb_each_other(conv_mode):
-    """Regression guard for the gfx950 hazard DESIGN.md describes: packed-fp32 VALU ops next to 16-bit MFMAs
-    of another wave returned wrong values, so device code is built without them.  A gather-sum kernel on one
-    stream must give its solo result while conv kernels (fp32 / f16x3) run on another."""
+    """Determinism guard behind DESIGN.md section 4 (round 1 saw run-to-run differences when f16x3 convs overlapped other
+    streams in a build with packed-fp32 VALU ops; unexplained, not reproducible standalone): a gather-sum kernel on one
+    stream must give its solo result, bit for bit, while conv kernels (fp32 / f16x3) run on another."""
     import ctypes as C
     from eva_vos_amd import _lib
     for victim in (0, 1, 2):
