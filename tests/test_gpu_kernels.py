@@ -33,6 +33,11 @@ CONVS = [
     (2, 17, 23, 128, 128, 3, 1, 3, 0),
     (1, 31, 45, 256, 64, 3, 1, 0, 0),
     (3, 16, 20, 512, 192, 3, 1, 2, 0),
+    (1, 6, 5, 128, 64, 3, 1, 1, 0),         # 9 tiles in one padded workgroup tile, split over input channels
+    # pointwise instance (1x1, stride 1): ragged M, residual + ReLU, split-K, and the stride-2 1x1 that must NOT take it
+    (2, 19, 21, 256, 192, 1, 1, 2, 0),
+    (1, 30, 54, 512, 128, 1, 1, 0, 3),
+    (2, 30, 54, 256, 512, 1, 2, 2, 0),
 ]
 
 

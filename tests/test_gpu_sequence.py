@@ -452,3 +452,20 @@ def test_multi_object_decode_groups_equal_the_frame_by_frame_path(nets, monkeypa
         assert iou(outs[0][0] == o, outs[1][0] == o) >= 1 - 1e-3 and iou(outs[0][1] == o, outs[1][1] == o) >= 1 - 1e-3
     d = (outs[0][2] - outs[1][2]).abs()
     assert float(torch.quantile(d.flatten()[::3].float(), 0.999)) < 1e-3, float(d.max())
+
+
+def test_eight_objects_is_the_engine_maximum_and_works(nets):
+    """k = 8 (the engine's stated maximum; decode groups shrink to 2 frames so that objects x frames <= 16): probabilities
+    are a distribution, every object keeps pixels, a repeat is bit-identical; k = 9 is refused with a message."""
+    T, H, W, k = 6, 128, 160, 8
+    img, msk = synth.synthetic_clip(T, H, W, seed=11), synth.synthetic_mask(T, H, W, k, seed=12)
+    m0 = torch.cat([1 - msk[:, 0].sum(0, keepdim=True).clamp(0, 1), msk[:, 0]], 0)
+    outs = []
+    for _ in range(2):
+        core = make_core(nets)(img, k, 3)
+        outs.append((core.interact(m0, 0, scribble=True).copy(), core.prob.clone()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert (outs[0][1][:, 1:].sum(0) - 1).abs().max() < 1e-5
+    assert set(np.unique(outs[0][0])) <= set(range(k + 1))
+    with pytest.raises(RuntimeError, match="1<=k<=8"):
+        make_core(nets)(img, 9, 3)
