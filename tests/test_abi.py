@@ -74,3 +74,27 @@ def test_engine_needs_gpu_and_never_falls_back(nets):
     from eva_vos_amd.inference_core import InferenceCore
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         InferenceCore(nets[0], nets[1], torch.zeros(1, 2, 3, 64, 64), 1)
+
+
+def test_fastdiv_magic_numbers_are_exact():
+    """csrc/kernels.h replaces run-time integer divisions by q = umulhi(x, magic) >> shift with magic = floor(2^(31+s)/d) + 1,
+    s = ceil(log2 d) (addresses depend on it).  The same formula restated here must equal x // d for every divisor that can
+    occur (tile counts, OH*OW, OW up to a few million) on boundary and random numerators below 2^31."""
+    rng = np.random.default_rng(0)
+
+    def make(d):
+        s = 0
+        while (1 << s) < d:
+            s += 1
+        return ((1 << (31 + s)) // d + 1) & 0xFFFFFFFF, s - 1
+
+    divisors = list(range(2, 3000)) + [2 ** k for k in range(1, 24)] + [2 ** k + 1 for k in range(1, 24)] + \
+        [25920, 103680, 1620, 6480, 32448, 129600, 518400, 2073600] + rng.integers(2, 1 << 23, 500).tolist()
+    for d in divisors:
+        magic, shift = make(d)
+        assert magic < (1 << 32)
+        xs = np.concatenate([np.array([0, 1, d - 1, d, d + 1, 2 * d - 1, (1 << 31) - 1, (1 << 31) - d, ((1 << 31) // d) * d - 1]),
+                             rng.integers(0, 1 << 31, 64)]).astype(np.uint64)
+        xs = xs[xs < (1 << 31)]
+        q = ((xs * np.uint64(magic)) >> np.uint64(32)) >> np.uint64(shift)
+        assert np.array_equal(q, xs // np.uint64(d)), d
