@@ -113,7 +113,11 @@ struct WinoG {
     FastDiv fd_tpi, fd_tw, fd_ntile, fd_tiles_n;
 };
 
-__global__ __launch_bounds__(512) void wino_gemm_kernel(const WinoG p, const int tiles_n, const int ntile) {
+// PPW positions per wave: 2 -> 8 waves (512 threads), 1 -> 16 waves (1024 threads, 4 per SIMD: more independent instruction
+// streams to keep the matrix pipe fed while a wave waits for its fragments)
+template <int PPW>
+__global__ __launch_bounds__(1024 / PPW) void wino_gemm_kernel(const WinoG p, const int tiles_n, const int ntile) {
+    constexpr int NT = 1024 / PPW;                                          // threads per workgroup
     extern __shared__ __attribute__((aligned(16))) float smem[];          // epilogue: [16][64][32]
     const int nblk = gridDim.x;
     auto xcd_contiguous = [](int bid, int nb) {
@@ -124,15 +128,15 @@ __global__ __launch_bounds__(512) void wino_gemm_kernel(const WinoG p, const int
     const int split = fastdiv(swz, p.fd_ntile), tile = swz - split * ntile;
     const int tm = fastdiv(tile, p.fd_tiles_n), tn = tile - tm * tiles_n;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, h = lane >> 5;
-    const int pos0 = 2 * wave;
+    const int pos0 = PPW * wave;
     const int kb0 = split * p.kb_per_split, kb1 = min(p.KB, kb0 + p.kb_per_split);
     const int nk = kb1 - kb0;
 
     const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.V), 0, p.v_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.U), 0, p.u_bytes, 0x00020000);
-    unsigned va[2][2], vb[2][2];
+    unsigned va[PPW][2], vb[PPW][2];
 #pragma unroll
-    for (int pi = 0; pi < 2; ++pi)
+    for (int pi = 0; pi < PPW; ++pi)
 #pragma unroll
         for (int bi = 0; bi < 2; ++bi) {
             va[pi][bi] = (unsigned)((((pos0 + pi) * p.KB + kb0) * (long)p.Mt_pad + tm * WT + 32 * bi + l31) * 32 + h * 16);
@@ -140,9 +144,9 @@ __global__ __launch_bounds__(512) void wino_gemm_kernel(const WinoG p, const int
         }
     const unsigned sa = (unsigned)p.Mt_pad * 32u, sb = (unsigned)p.N * 32u;   // bytes per k-block
 
-    f32x16 acc[2][2][2];
+    f32x16 acc[PPW][2][2];
 #pragma unroll
-    for (int pi = 0; pi < 2; ++pi)
+    for (int pi = 0; pi < PPW; ++pi)
 #pragma unroll
         for (int bi = 0; bi < 2; ++bi)
 #pragma unroll
@@ -150,21 +154,21 @@ __global__ __launch_bounds__(512) void wino_gemm_kernel(const WinoG p, const int
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[pi][bi][bj][e] = 0.f;
 
-    auto load = [&](int k, f32x4 (&fa)[2][2], f32x4 (&fb)[2][2]) {
+    auto load = [&](int k, f32x4 (&fa)[PPW][2], f32x4 (&fb)[PPW][2]) {
         const unsigned oa = (unsigned)k * sa, ob = (unsigned)k * sb;
 #pragma unroll
-        for (int pi = 0; pi < 2; ++pi)
+        for (int pi = 0; pi < PPW; ++pi)
 #pragma unroll
             for (int bi = 0; bi < 2; ++bi) {
                 fa[pi][bi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rv, va[pi][bi], oa, 0));
                 fb[pi][bi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ru, vb[pi][bi], ob, 0));
             }
     };
-    auto compute = [&](const f32x4 (&fa)[2][2], const f32x4 (&fb)[2][2]) {
+    auto compute = [&](const f32x4 (&fa)[PPW][2], const f32x4 (&fb)[PPW][2]) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int pi = 0; pi < 2; ++pi)
+            for (int pi = 0; pi < PPW; ++pi)
 #pragma unroll
                 for (int bi = 0; bi < 2; ++bi)
 #pragma unroll
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(512) void wino_gemm_kernel(const WinoG p, const int
         // blocks (2 x 32 MFMAs x 2 waves per SIMD ~ 3.5 us) to arrive - V streams from HBM at the big layers.
         // sched_barrier pins "all 8 loads, THEN the 32 MFMAs": left alone hipcc sinks most loads to the end of the MFMA
         // block, right in front of their first use
-        f32x4 fa0[2][2], fb0[2][2], fa1[2][2], fb1[2][2], fa2[2][2], fb2[2][2];
+        f32x4 fa0[PPW][2], fb0[PPW][2], fa1[PPW][2], fb1[PPW][2], fa2[PPW][2], fb2[PPW][2];
         load(0, fa0, fb0);
         load(min(1, nk - 1), fa1, fb1);
         int k = 0;
@@ -199,12 +203,13 @@ __global__ __launch_bounds__(512) void wino_gemm_kernel(const WinoG p, const int
     }
 
     // ---- epilogue: 32 output channels at a time through LDS, Y = A^T M A
-    const int n_l = t & 31, tsub = t >> 5;                                  // thread -> (channel, tiles tsub + 16 q)
+    constexpr int TS = NT / 32, NQ = WT / TS;                               // tiles per pass of the thread block, passes
+    const int n_l = t & 31, tsub = t >> 5;                                  // thread -> (channel, tiles tsub + TS q)
     const int tpi = p.TH * p.TW, ohw = p.OH * p.OW;
-    int tb[4], toh[4], tow[4];                                              // batch element and first output pixel of the 4 tiles
+    int tb[NQ], toh[NQ], tow[NQ];                                              // batch element and first output pixel of the 4 tiles
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const long gt = (long)tm * WT + tsub + 16 * q;
+    for (int q = 0; q < NQ; ++q) {
+        const long gt = (long)tm * WT + tsub + TS * q;
         const int b = gt < p.Mt ? fastdiv((int)gt, p.fd_tpi) : -1;
         const int rr = (int)(gt - (long)(b < 0 ? 0 : b) * tpi);
         const int ty = fastdiv(rr, p.fd_tw);
@@ -214,7 +219,7 @@ __global__ __launch_bounds__(512) void wino_gemm_kernel(const WinoG p, const int
     for (int c = 0; c < 2; ++c) {
         __syncthreads();
 #pragma unroll
-        for (int pi = 0; pi < 2; ++pi)
+        for (int pi = 0; pi < PPW; ++pi)
 #pragma unroll
             for (int bi = 0; bi < 2; ++bi)
 #pragma unroll
@@ -224,8 +229,8 @@ __global__ __launch_bounds__(512) void wino_gemm_kernel(const WinoG p, const int
         const int n = tn * WN + 32 * c + n_l;
         const float bv = (p.bias && p.splitk == 1) ? p.bias[n] : 0.f;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int tl = tsub + 16 * q;
+        for (int q = 0; q < NQ; ++q) {
+            const int tl = tsub + TS * q;
             float m[16];
 #pragma unroll
             for (int ps = 0; ps < 16; ++ps) m[ps] = smem[(ps * WT + tl) * 32 + n_l];
@@ -329,11 +334,23 @@ void wino_launch(const ConvP &p, float *V, size_t slab_floats, hipStream_t s, hi
     g.kb_per_split = (KB + sk - 1) / sk;
     g.splitk = sk; g.partial = p.partial;
     const size_t lds = (size_t)16 * WT * 32 * sizeof(float);
-    allow_big_lds(reinterpret_cast<const void *>(&wino_gemm_kernel), lds);
-    if (ev_gemm)
-        hipExtLaunchKernelGGL(wino_gemm_kernel, dim3(ntile * sk), dim3(512), lds, s, ev_gemm[0], ev_gemm[1], 0, g, tiles_n, ntile);
-    else
-        hipLaunchKernelGGL(wino_gemm_kernel, dim3(ntile * sk), dim3(512), lds, s, g, tiles_n, ntile);
+    // 16 waves x 1 position (4 waves per SIMD) feed the matrix pipe a little better on the short-K layers (+1.5-3 % up to 512
+    // input channels); with 1024+ channels the 8-wave form with its deeper per-wave prefetch is as good or better
+    static const int ppw_env = [] { const char *e = getenv("STCN_WINO_PPW"); return e ? atoi(e) : 0; }();
+    const int ppw = ppw_env ? ppw_env : (p.Cin <= 512 ? 1 : 2);
+    if (ppw == 1) {
+        allow_big_lds(reinterpret_cast<const void *>(&wino_gemm_kernel<1>), lds);
+        if (ev_gemm)
+            hipExtLaunchKernelGGL(wino_gemm_kernel<1>, dim3(ntile * sk), dim3(1024), lds, s, ev_gemm[0], ev_gemm[1], 0, g, tiles_n, ntile);
+        else
+            hipLaunchKernelGGL(wino_gemm_kernel<1>, dim3(ntile * sk), dim3(1024), lds, s, g, tiles_n, ntile);
+    } else {
+        allow_big_lds(reinterpret_cast<const void *>(&wino_gemm_kernel<2>), lds);
+        if (ev_gemm)
+            hipExtLaunchKernelGGL(wino_gemm_kernel<2>, dim3(ntile * sk), dim3(512), lds, s, ev_gemm[0], ev_gemm[1], 0, g, tiles_n, ntile);
+        else
+            hipLaunchKernelGGL(wino_gemm_kernel<2>, dim3(ntile * sk), dim3(512), lds, s, g, tiles_n, ntile);
+    }
     if (sk > 1) {
         ConvP q = p;
         q.splitk = sk;
