@@ -18,7 +18,7 @@ Output: ONE JSON line on rank 0 (see the task contract) with two extra objects:
                  this box's host cores on a bounded sample of BASELINE config 1 (both rounds), rank 0 at N=1 only.
 Further objects (not the headline): roofline_memread (the space-time memory read at config-3 scale, MFMA fraction on
 2*N*Q*64 and GB/s on SURVEY 8(d)'s algorithmic bytes), config3 (k=5, mem_freq=1, T=104: the full-bank multi-object
-case), extra_f16x3_leg, r2_frames_per_s_rank0.  Real data: when ./model_weights/mivos/{stcn,fusion}.pth and
+case), roofline_r2 (a second interaction: cached keys + fusion), davis_val (30 DAVIS-val lengths, LPT over ranks).  Real data: when ./model_weights/mivos/{stcn,fusion}.pth and
 ./data/DAVIS_17 exist the same line is measured on real DAVIS-17-val clips with "data": "real" (there is no network
 here, so the default is the synthetic recipe and the line says so).
 """
@@ -42,16 +42,25 @@ FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=None, help="ranks (one per GPU); default = WORLD_SIZE or 1")
-    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=None, help="videos per rank (uniform workload, default 12) / samples of the whole job (davis-val, default 30)")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=66, help="frames per video (DAVIS-17 val mean length ~66)")
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=854)
     ap.add_argument("--mem-freq", type=int, default=5)
     ap.add_argument("--objects", type=int, default=1, help="k>1: multi-object engine via the scribble/(k+1)-channel path (config 3)")
-    ap.add_argument("--cpu-frames", type=int, default=41,
-                    help="frames of the bounded CPU-oracle sample: BASELINE config 1 is T=82, interact(0) then interact(41); the default "
-                         "runs the same two rounds on a T=41 clip (interact(0), interact(20)); 82 = the full config; 0 = skip")
+    ap.add_argument("--cpu-frames", type=int, default=82,
+                    help="frames of the bounded CPU-oracle sample: BASELINE config 1 is T=82, interact(0) then interact(41) = the "
+                         "default (about 60 s of host time); smaller = the same two rounds on a shorter clip; 0 = skip")
+    ap.add_argument("--workload", choices=("uniform", "davis-val"), default="uniform",
+                    help="uniform (default, the headline): every rank runs --steps videos of --frames frames (weak scaling).  davis-val: "
+                         "the whole JOB runs --steps samples (default 30) whose lengths are the 30 DAVIS-2017-val sequence lengths "
+                         "(34..104 frames), assigned to the ranks by LPT (strong scaling: SURVEY 8(d) config 2 / 8(e))")
+    ap.add_argument("--davis-max-frames", type=int, default=104, help="clamp the DAVIS-val lengths (tests run tiny clips)")
+    ap.add_argument("--no-davis-val", dest="davis_val", action="store_false",
+                    help="skip the extra davis_val object (the 30-length workload measured beside the uniform headline)")
+    ap.add_argument("--config3-oracle-frames", type=int, default=8,
+                    help="frames of the config-3 parity sample (k objects, mem_freq=1) run on the CPU oracle AND the HIP engine; 0 = skip")
     ap.add_argument("--no-config3", dest="config3", action="store_false",
                     help="skip the extra config-3 leg (k=5 objects, mem_freq=1, T=104: full-length bank)")
     ap.add_argument("--config3-frames", type=int, default=104)
@@ -63,10 +72,6 @@ def parse():
     ap.add_argument("--no-profile", action="store_true", help="skip the roofline leg (roofline = null)")
     ap.add_argument("--roof-steps", type=int, default=1, help="videos of the profiled single-stream roofline leg")
     ap.add_argument("--streams", type=int, default=4, help="videos in flight per GPU (one host thread + HIP stream each)")
-    ap.add_argument("--f16x3-leg", dest="f16x3_leg", action="store_true", default=False,
-                    help="also run the extra (non-headline) f16x3 split-precision leg (opt-in since round 2: with the 3x3 convs on "
-                         "Winograd the exact-fp32 default is faster than this mode, which still runs direct convs)")
-    ap.add_argument("--no-f16x3-leg", dest="f16x3_leg", action="store_false", help="(default) skip the f16x3 leg")
     ap.add_argument("--no-r2", dest="r2", action="store_false",
                     help="skip the extra R2 number (a second interaction: cached keys + fusion; reported, not the headline)")
     return ap.parse_args()
@@ -137,6 +142,11 @@ def parity_vs_oracle(prop, fuse, sample, mem_freq):
         union = (a_ | b_).sum()
         out[f"mask_iou_hip_vs_cpu_oracle_{tag}"] = float((a_ & b_).sum() / union) if union else 1.0
         out[f"mask_pixels_differing_{tag}"] = int((a_ != b_).sum())
+        # per FRAME (a clip-volume IoU hides one bad frame among many): the worst frame and where it is
+        fu, fi = (a_ | b_).reshape(len(a_), -1).sum(1), (a_ & b_).reshape(len(a_), -1).sum(1)
+        fiou = np.where(fu >= 64, fi / np.maximum(fu, 1), 1.0)
+        out[f"min_frame_iou_hip_vs_cpu_oracle_{tag}"] = float(fiou.min())
+        out[f"min_frame_iou_frame_{tag}"] = int(fiou.argmin())
     out["mask_pixels_total"] = int(got1.size)
     # interacted frames carry no propagated mask (the callers overwrite them): score the others
     keep = np.ones(img.shape[1], bool)
@@ -243,6 +253,163 @@ def config3_leg(prop, fuse, T, H, W, k):
             "memread_algorithmic_gbytes_per_s": mr["bytes"] / (mr["ms"] * 1e-3) / 1e9}
 
 
+# the 30 sequences of DAVIS-2017 val (bike-packing ... soapbox): frames per sequence, 1999 in all (mean 66.6)
+DAVIS_VAL_LENGTHS = [69, 50, 80, 84, 90, 75, 40, 104, 90, 60, 66, 52, 50, 90, 78, 50, 81, 34, 50, 47, 49, 50, 79, 40, 80, 100, 79, 43, 40, 99]
+
+
+def config3_parity(prop, fuse, psd, fsd, T, H, W, k):
+    """BASELINE config 3's shape on the CPU oracle AND the HIP engine (first T frames: k objects through the scribble path,
+    mem_freq = 1): per-object mask IoU - over all pixels and over the pixels whose label is well-conditioned in the ORACLE's
+    own probabilities (top-1 minus top-2 >= 1e-3; with several objects the random-recipe decoder leaves large regions at
+    p ~ 1/(k+1) in every row, where the argmax hangs on the last ulp: tests/test_oracle_golden.py, seq480k5) - the worst
+    frame, and the probability difference."""
+    from eva_vos_amd import synth
+    from mivos.inference_core import InferenceCore
+    from oracle.stcn_oracle import OracleCore
+    img, gt = synth.synthetic_clip(T, H, W), synth.synthetic_mask(T, H, W, k)
+    m0 = torch.cat([1 - gt[:, 0].sum(0, keepdim=True).clamp(0, 1), gt[:, 0]], 0)
+    t0 = time.perf_counter()
+    orc = OracleCore(psd, fsd, img, k, mem_freq=1)
+    ref = orc.interact(m0.clone(), 0, scribble=True)
+    t_cpu = time.perf_counter() - t0
+    core = InferenceCore(prop, fuse, img.cuda(), k, mem_freq=1)
+    got = core.interact(m0, 0, scribble=True)
+    lw, uw, lh, uh = orc.pad
+    crop = lambda p_: p_[:, :, 0, lh:p_.shape[3] - uh if uh else None, lw:p_.shape[4] - uw if uw else None]      # noqa: E731
+    po, pg = crop(orc.prob), crop(core.prob.cpu())
+    top = torch.topk(po, 2, dim=0).values
+    dec = ((top[0] - top[1]) >= 1e-3).numpy()
+    d = (po - pg).abs()
+    out = dict(sample=f"first {T} frames of the config-3 workload ({H}x{W}, k={k}, mem_freq=1), interact(mask,0): CPU oracle {t_cpu:.1f} s",
+               decisive_pixel_fraction=float(dec[1:].mean()), mask_pixels_differing=int((got != ref).sum()),
+               mask_pixels_differing_on_decisive=int(((got != ref) & dec).sum()), mask_pixels_total=int(got.size),
+               prob_abs_diff_p999=float(torch.quantile(d.flatten()[::7], 0.999)), prob_abs_diff_max=float(d.max()))
+    ious, ious_dec, fmin = [], [], 1.0
+    for o in range(1, k + 1):
+        a_, b_ = got == o, ref == o
+        ious.append(float((a_ & b_).sum() / max((a_ | b_).sum(), 1)))
+        a_, b_ = a_ & dec, b_ & dec
+        ious_dec.append(float((a_ & b_).sum() / max((a_ | b_).sum(), 1)))
+        fu, fi = (a_ | b_).reshape(T, -1).sum(1), (a_ & b_).reshape(T, -1).sum(1)
+        fmin = min(fmin, float(np.where(fu >= 64, fi / np.maximum(fu, 1), 1.0).min()))
+    out.update(mask_iou_vs_cpu_oracle_per_object=ious, mask_iou_vs_cpu_oracle_per_object_decisive_pixels=ious_dec,
+               mask_iou_vs_cpu_oracle=min(ious_dec), min_frame_iou_decisive_pixels=fmin,
+               what="mask_iou_vs_cpu_oracle = worst object on the decisive pixels (bar 1 - 1e-3); the all-pixel IoU is given beside it")
+    del core
+    torch.cuda.empty_cache()
+    return out
+
+
+def r2_roofline(prop, fuse, img, mask0, mask_mid, T, mem_freq, scribble):
+    """The regime the reference's annotation loops spend their time in (59 of 60 rounds of eval_annotation_method.py:30, 7 of 8 of
+    interactions/mask.py:113-146): a SECOND interaction - cached key features, memory read + decoder on every frame,
+    FusionNet + attention read on the frames between the two interacted frames (inference_core.py:184-207).  One video, one
+    stream, HIP events per launch (same method as `roofline`)."""
+    from mivos.inference_core import InferenceCore
+    la_saved = os.environ.get("STCN_LOOKAHEAD")
+    os.environ["STCN_LOOKAHEAD"] = "0"
+    res = {}
+    for prof_on in (False, True):
+        e = InferenceCore(prop, fuse, img, 1 if not scribble else mask0.shape[0] - 1, mem_freq=mem_freq)
+        e.interact(mask0, 0, scribble=scribble)
+        e.set_profiling(prof_on)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e.interact(mask_mid, T // 2, scribble=scribble)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        st = e.stats()
+        if not prof_on:
+            res["frames_per_s_solo"] = st["frames"] / dt
+        else:
+            prof = e.kernel_profile()
+            prof.pop("conv_hbm_bound")
+        del e
+    if la_saved is None:
+        os.environ.pop("STCN_LOOKAHEAD")
+    else:
+        os.environ["STCN_LOOKAHEAD"] = la_saved
+    tot = sum(v["ms"] for v in prof.values())
+    conv, fus = prof["conv"], prof["fusion_conv"]
+    gemm_ms = conv["ms"] + fus["ms"]
+    ach = (conv["exec_flops"] + fus["exec_flops"]) / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    all_ms = gemm_ms + prof["wino_input"]["ms"] + prof["conv_reduce"]["ms"]
+    res.update({"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS,
+                "traffic": None,
+                "what": "R2 = interact(mask, T//2) after interact(mask, 0): executed MFMA FLOP of all conv GEMM launches (decoder / value "
+                        "encoder + FusionNet) / their summed device time",
+                "frames": st["frames"], "fused_frames": st["fused"], "value_encodes": st["value_enc"], "key_misses": st["key_miss"],
+                "kernel_ms_per_frame": tot / max(st["frames"], 1),
+                "kernel_time_share": {c: round(v["ms"] / tot, 4) for c, v in prof.items() if v["ms"] > 0},
+                "decoder_value_conv_executed_tflops": conv["exec_flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0,
+                "fusion_conv_tflops": fus["flops"] / (fus["ms"] * 1e-3) / 1e12 if fus["ms"] > 0 else 0.0,
+                "fusion_conv_ms_per_fused_frame": fus["ms"] / max(st["fused"], 1),
+                "fusion_conv_launches": fus["launches"],
+                "algorithmic_tflops_incl_transforms": (conv["flops"] + fus["flops"]) / (all_ms * 1e-3) / 1e12 if all_ms > 0 else 0.0,
+                "algorithmic_gflop_per_frame": sum(v["flops"] for v in prof.values()) / max(st["frames"], 1) / 1e9,
+                "memread_share": round(prof["memread"]["ms"] / tot, 4), "attention_share": round(prof["attention"]["ms"] / tot, 4)})
+    return res
+
+
+def davis_val_leg(prop, fuse, a, H, W, rank, world, local, streams, barrier):
+    """samples with the 30 DAVIS-2017-val sequence lengths, assigned to the ranks by LPT on their
+    frame counts (eva_vos_amd.shard.lpt_assign; the reference slices by --min-idx/--max-idx, eval_annotation_method.py:34-35,
+    113-119), inside a rank to the in-flight lanes the same way.  Fixed total work -> strong scaling: frames of ALL samples /
+    the slowest rank's time, with the per-rank busy fraction and the imbalance the tail lengths (34..104) cause."""
+    import threading
+    from eva_vos_amd import shard, synth
+    from mivos.inference_core import InferenceCore
+    n = a.steps if a.workload == "davis-val" else len(DAVIS_VAL_LENGTHS)
+    lengths = [min(DAVIS_VAL_LENGTHS[i % len(DAVIS_VAL_LENGTHS)], a.davis_max_frames) for i in range(n)]
+    assign = shard.lpt_assign([t - 1 for t in lengths], world)
+    mine = assign[rank]
+    S = len(streams)
+    lanes = [[mine[j] for j in part] for part in shard.lpt_assign([lengths[i] - 1 for i in mine], S)]
+    Tmax = max(lengths)
+    base = synth.synthetic_clip(Tmax, H, W).cuda()
+    mask0 = synth.synthetic_mask(Tmax, H, W, 1)[:, 0].clone()
+    engines = {}
+    for l, part in enumerate(lanes):
+        with torch.cuda.stream(streams[l]):
+            for i in part:
+                g = torch.Generator(device="cuda").manual_seed(5000 + i)
+                clip = base[:, :lengths[i]] + 0.15 * torch.randn((1, lengths[i]) + tuple(base.shape[2:]), generator=g, device="cuda")
+                engines[i] = InferenceCore(prop, fuse, clip, 1, mem_freq=a.mem_freq)
+    del base
+    torch.cuda.synchronize()
+    frames = [0] * S
+
+    def run(l):
+        torch.cuda.set_device(local)
+        with torch.cuda.stream(streams[l]):
+            for i in lanes[l]:                               # longest first (LPT order)
+                engines[i].interact(mask0, 0)
+                frames[l] += engines[i].stats()["frames"]
+
+    barrier()
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=run, args=(l,)) for l in range(S)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    torch.cuda.synchronize()
+    t_rank = time.perf_counter() - t0
+    barrier()
+    rows = shard.gather_rows(np.array([[rank, t_rank, sum(frames), len(mine)]], np.float64), 4)
+    engines.clear()
+    torch.cuda.empty_cache()
+    t_max = float(rows[:, 1].max())
+    total = float(rows[:, 2].sum())
+    per_rank_frames = [sum(lengths[i] - 1 for i in part) for part in assign]
+    return {"workload": f"{n} single-object {H}x{W} samples with the DAVIS-2017-val sequence lengths ({min(lengths)}..{max(lengths)} frames, "
+                        f"{sum(lengths)} in all), fresh engine + interact(mask,0) each, mem_freq={a.mem_freq}; LPT over {world} rank(s), "
+                        f"{S} lane(s) per rank", "scaling": "strong",
+            "samples": n, "frames_total": total, "frames_per_s": total / t_max, "slowest_rank_s": t_max,
+            "rank_seconds": [float(v) for v in rows[:, 1]], "rank_busy_fraction": [float(v / t_max) for v in rows[:, 1]],
+            "rank_frames": per_rank_frames, "rank_samples": [len(p_) for p_ in assign],
+            "imbalance_max_over_mean_frames": max(per_rank_frames) / (sum(per_rank_frames) / world),
+            "lengths_by_rank": [[lengths[i] for i in part] for part in assign]}
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` outside torch.distributed.run: this process - which has not touched the GPU (no
     torch.cuda call, libstcn_hip.so not loaded) - starts N fresh rank processes through torch.distributed.run (one per
@@ -261,6 +428,8 @@ def launch_ranks(n):
 
 def main():
     a = parse()
+    if a.steps is None:
+        a.steps = 12 if a.workload == "uniform" else len(DAVIS_VAL_LENGTHS)
     if a.gpus is not None and a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(a.gpus))
     rank = int(os.environ.get("RANK", 0))
@@ -319,7 +488,9 @@ def main():
     mask_mid = as_input(gt[:, T // 2])
 
     # one HIP stream per in-flight video; engines are bound to the stream they are created under
-    S = max(1, min(a.streams, a.steps))
+    # davis-val as the headline: the uniform region below only warms the kernels up (one video per lane)
+    n_uniform = a.steps if a.workload == "uniform" else max(1, min(a.steps, a.streams))
+    S = max(1, min(a.streams, n_uniform))
     # engine knob: key-encoder look-ahead on a side stream helps a single video in flight (+6 %) but only
     # adds contention when several videos already overlap
     os.environ.setdefault("STCN_LOOKAHEAD", "0" if S > 1 else "2")
@@ -371,7 +542,7 @@ def main():
             while True:
                 with lock:
                     j = next(ticket)
-                if j >= a.steps:
+                if j >= n_uniform:
                     break
                 e = pool[lane][n % per_lane]
                 if fresh:
@@ -438,46 +609,34 @@ def main():
             del e
         os.environ["STCN_LOOKAHEAD"] = la_saved
 
-    # Extra leg (not the headline): the same timed region with the convs on the f16 MFMA pipe through the
-    # 3-term fp16 hi/lo operand split (fp32 accumulate, fp32-grade products; DESIGN.md "f16x3"), and how many
-    # mask pixels differ from the exact-fp32 run above.
-    extra = None
-    if a.f16x3_leg and world == 1 and os.environ.get("STCN_PRECISION") is None:
-        pool_main = pool
-        os.environ["STCN_PRECISION"] = "f16x3"
-        prop_main, prop = prop, PropagationNetwork()
-        prop.load_state_dict(psd)
-        pool = [[make(l, j) for j in range(per_lane)] for l in range(S)]
-        run_all(mask0, 0)                                  # warm-up (one video per lane)
-        torch.cuda.synchronize()
-        tx = time.perf_counter()
-        resx = run_all(mask0, 0)
-        torch.cuda.synchronize()
-        dtx = time.perf_counter() - tx
-        extra = {"precision": "f16x3: fp16 hi/lo split operands, 3 x v_mfma_f32_32x32x16_f16 per K step, fp32 accumulate",
-                 "frames_per_s_rank0": sum(r[0] for r in resx) / dtx,
-                 # the same clip in both precisions: engine 0 of the first lane that ran a video in both legs
-                 "mask_pixels_differing_from_fp32_run": next(int((rx[4][0] != r[4][0]).sum()) for rx, r in zip(resx, res) if 0 in rx[4] and 0 in r[4]),
-                 "mask_pixels_total": int(last.size)}
-        os.environ.pop("STCN_PRECISION")
-        pool, prop = pool_main, prop_main
-
-    r2 = None
+    r2, r2_roof = None, None
     if a.r2:
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         res2 = run_all(mask_mid, T // 2, fresh=False)     # second interaction on the engines' last videos
         torch.cuda.synchronize()
         r2 = sum(r[0] for r in res2) / (time.perf_counter() - t1)
+        if not a.no_profile and rank == 0:
+            r2_roof = r2_roofline(prop, fuse, img, mask0, mask_mid, T, a.mem_freq, K_OBJ > 1)
+            r2_roof["frames_per_s_videos_in_flight"] = r2
+
+    # Extra leg: the DAVIS-val-shaped workload (30 samples, lengths 34..104, LPT over the ranks): what SURVEY 8(d) calls
+    # config 2 and 8(e) names as the scaling risk (tail imbalance).  The pooled engines are released first (HBM).
+    del pool, clips
+    torch.cuda.empty_cache()
+    dv = None
+    if (a.davis_val or a.workload == "davis-val") and real is None and K_OBJ == 1:
+        dv = davis_val_leg(prop, fuse, a, H, W, rank, world, local, streams, barrier)
 
     # Extra leg: BASELINE config 3 at its stated size - one multi-object engine (k objects through the scribble /
     # (k+1)-channel path, the only multi-object path of the reference: inference_core.py:220-233), mem_freq = 1 (every
     # frame enters the bank: full-length memory, bank rows up to T * 1620), T = 104 (the longest clip, download_data.py:42).
     cfg3 = None
     if a.config3 and world == 1 and real is None:
-        del pool, clips
-        torch.cuda.empty_cache()
         cfg3 = config3_leg(prop, fuse, a.config3_frames, H, W, a.config3_objects)
+        if a.config3_oracle_frames > 1:
+            cfg3["parity_vs_cpu_oracle"] = config3_parity(prop, fuse, psd, fsd, a.config3_oracle_frames, H, W, a.config3_objects)
+            cfg3["mask_iou_vs_cpu_oracle"] = cfg3["parity_vs_cpu_oracle"]["mask_iou_vs_cpu_oracle"]
     mr_roof = memread_roofline(a.config3_objects) if (a.memread_roofline and world == 1) else None
 
     # whole-job numbers: max time over ranks, frames summed over ranks
@@ -500,14 +659,14 @@ def main():
             "metric": "frames/sec STCN mask-propagate 480p 1-obj",
             "value": frames_all / dt_all, "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": 1e3 * dt_all / a.steps,
+            "ms_per_step": 1e3 * dt_all / n_uniform,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if os.environ.get("STCN_PRECISION") != "f16x3" else "f16x3 (fp16 hi/lo split operands, f32 accumulate)",
+            "dtype": "f32",
             "data": "real" if real is not None else "synthetic",
             "config": {"workload": f"{'DAVIS-17 val clip ' + real['name'] if real is not None else 'DAVIS-17-val-shaped'} {H}x{W} (padded {pad_hw[0]}x{pad_hw[1]}) {'single' if K_OBJ == 1 else K_OBJ}-object "
                                    f"STCN propagate: fresh engine, interact(mask,0), T={T} frames/video, "
                                    f"mem_freq={a.mem_freq}, top_k=50; one video per step per GPU",
-                       "frames_per_step": T - 1, "videos_per_gpu": a.steps, "sharding": f"videos x{world}", "streams_per_gpu": S,
+                       "frames_per_step": T - 1, "videos_per_gpu": n_uniform, "sharding": f"videos x{world}", "streams_per_gpu": S,
                        "key_lookahead": int(os.environ["STCN_LOOKAHEAD"]),
                        "clips": f"{S * per_lane} distinct synthetic clips (one per pooled engine)",
                        "weights": "model_weights/mivos/stcn.pth + fusion.pth" if real is not None else "synthetic recipe seed 0 (no checkpoints offline)"},
@@ -517,8 +676,15 @@ def main():
         }
         if r2 is not None:
             out["r2_frames_per_s_rank0"] = r2
-        if extra is not None:
-            out["extra_f16x3_leg"] = extra
+        if r2_roof is not None:
+            out["roofline_r2"] = r2_roof
+        if dv is not None:
+            out["davis_val"] = dv
+            if a.workload == "davis-val":      # this workload as the headline: fixed total work, strong scaling
+                out.update(value=dv["frames_per_s"], scaling="strong", ms_per_step=1e3 * dv["slowest_rank_s"] / dv["samples"],
+                           steps=dv["samples"], uniform_region_frames_per_s=frames_all / dt_all)
+                out["config"]["workload"] = dv["workload"]
+                out["config"]["sharding"] = f"LPT over {world} rank(s)"
         if prof is not None:
             conv, wi, rd = prof["conv"], prof["wino_input"], prof["conv_reduce"]
             # Dominant kernels: the two fp32-MFMA conv GEMMs (conv_gemm_kernel: direct implicit GEMM; wino_gemm_kernel: the
@@ -556,10 +722,12 @@ def main():
                                            "what": "conv launches under 19.7 FLOP/B of algorithmic intensity (1x1 channel expansions, stems)"}}
             # HBM-side bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate runs)
             try:
-                pmc_file = [f for f in ("r02_pmc_traffic.json", "r01_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
+                pmc_file = [f for f in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
                 pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
                 out["roofline"]["traffic"] = pmc["conv_gemm_traffic_bytes_per_launch"]
-                out["roofline"]["traffic_source"] = f"profiles/{pmc_file} (rocprofv3 --pmc passes of this workload at T=30: FETCH_SIZE x2 + WRITE_SIZE per conv GEMM launch)"
+                out["roofline"]["traffic_source"] = (f"profiles/{pmc_file}: a committed capture, NOT measured by this run (rocprofv3 --pmc passes of this "
+                                                     f"workload at T={pmc.get('frames', 30)}, FETCH_SIZE x2 + WRITE_SIZE per conv GEMM launch; captured at commit "
+                                                     f"{pmc.get('commit', 'unknown')}: {pmc.get('captured', 'round 2')})")
             except (OSError, IndexError):
                 pass
             out["roofline"]["algorithmic_bytes_per_launch"] = conv["bytes"] / max(conv["launches"], 1)

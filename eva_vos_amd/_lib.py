@@ -14,7 +14,7 @@ import torch  # noqa: F401  (first: PyTorch-ROCm bundles its own libamdhip64/lib
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libstcn_hip.so")
 
-K_CLASSES = ("conv", "conv_reduce", "memread", "elementwise", "conv_n1", "other", "wino_input")
+K_CLASSES = ("conv", "conv_reduce", "memread", "elementwise", "conv_n1", "other", "wino_input", "fusion_conv", "attention")
 
 
 class WeightDesc(C.Structure):
@@ -44,10 +44,11 @@ PROTOTYPES = {
     "stcn_test_encode_value": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "stcn_test_memory_read": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "stcn_bench_memory_read": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, C.POINTER(_F), C.POINTER(C.c_int32)]),
+    "stcn_memread_plan": (_I, [_I, _I, C.POINTER(C.c_int32)]),
+    "stcn_test_fail_at": (_I, [_I]),
     "stcn_test_decode": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
     "stcn_test_attention": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "stcn_test_fusion": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _I, _I, _P]),
-    "stcn_debug_overlap": (_I, [_I, _I, _I, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "stcn_metrics_jf_counts": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
     "stcn_bench_conv": (_I, [_P] + [_I] * 11 + [C.POINTER(_F), C.POINTER(_D)]),
     "stcn_engine_set_profiling": (_I, [_P, _I]),

@@ -375,7 +375,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvP p, const int
                 const unsigned v0 = (unsigned)(((long)mbase * p.N + n) * 4), n4 = (unsigned)p.N * 4u;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const unsigned vo = mbase < p.M ? v0 + (unsigned)((r & 3) + 8 * (r >> 2)) * n4 : OOB;
+                    // rows >= M lie at >= M*N*4 bytes, beyond the descriptor range (no wrap: (M + 128) * N * 4 < 4 GiB, run_conv)
+                    const unsigned vo = v0 + (unsigned)((r & 3) + 8 * (r >> 2)) * n4;
                     float v = c[r] + bv;
                     if (p.res) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, vo, 0, 0));
                     if (p.relu_out) v = fmaxf(v, 0.f);
@@ -499,7 +500,7 @@ static Plan plan_variant(const ConvP &p, bool big, int force_splitk, size_t ws_f
         if (cost < best.cost) best = Plan{cost, big ? 1 : 0, s, 0, 0, 0};
     }
     const long full_rounds = tiles / 256, n_rem = tiles - full_rounds * 256;
-    if (tail_on && force_splitk <= 0 && !(p.mode & 1) && full_rounds >= 1 && n_rem > 0 && nkt >= 8) {
+    if (tail_on && force_splitk <= 0 && full_rounds >= 1 && n_rem > 0 && nkt >= 8) {
         for (int sr = 2; sr <= 8 && sr <= nkt / 4; ++sr) {
             const int per = (nkt + sr - 1) / sr;
             if ((long)per * (sr - 1) >= nkt) continue;
@@ -516,13 +517,13 @@ static Plan plan_variant(const ConvP &p, bool big, int force_splitk, size_t ws_f
 void conv_plan(ConvP &p, int force_splitk, size_t ws_floats) {
     static const int big_mode = [] { const char *e = getenv("STCN_CONV_BIG"); return e ? atoi(e) : 1; }();
     Plan pl = plan_variant(p, false, force_splitk, ws_floats);
-    const bool big_ok = big_mode != 0 && !(p.mode & 1) && !narrow_variant(p) && !smallc_variant(p) && p.N >= 256 && p.Kp >= 2304;
+    const bool big_ok = big_mode != 0 && !narrow_variant(p) && !smallc_variant(p) && p.N >= 256 && p.Kp >= 2304;
     if (big_ok) {
         const Plan pb = plan_variant(p, true, force_splitk, ws_floats);
         if (pb.cost < pl.cost || big_mode >= 2) pl = pb;
     }
     static const int panel_env = [] { const char *e = getenv("STCN_CONV_PANEL"); return e ? atoi(e) : 4; }();
-    p.panel = (p.mode & 1) ? 0 : panel_env;
+    p.panel = panel_env;
     p.tile_big = pl.big; p.splitk = pl.splitk;
     p.rem_full = pl.rem_full; p.rem_split = pl.rem_split; p.rem_per = pl.rem_per;
     static const bool dbg = getenv("STCN_CONV_PLAN_DEBUG") != nullptr;
@@ -558,9 +559,7 @@ void conv_launch(const ConvP &p, hipStream_t s, hipEvent_t *ev_gemm, hipEvent_t 
     const int pn = p.panel;
     const TileDiv td{fastdiv_make((unsigned)ntile), fastdiv_make((unsigned)tiles_n), fastdiv_make((unsigned)(tiles_m * (pn > 0 ? pn : 1))), tiles_m};
     hipEvent_t e0 = ev_gemm ? ev_gemm[0] : nullptr, e1 = ev_gemm ? ev_gemm[1] : nullptr;
-    if (p.mode & 1) {
-        conv_f16x3_launch(p, tiles_n, ntile, per, grid, s, e0, e1);
-    } else {
+    {
 #define STCN_LAUNCH(WM_, WN_, RM_, RN_, SC_, RL_, ...)                                                                  \
     do {                                                                                                                 \
         auto kfn = conv_gemm_kernel<WM_, WN_, RM_, RN_, SC_, RL_, ##__VA_ARGS__>;                                        \

@@ -95,34 +95,9 @@ static int upload(Model &m, const std::vector<float> &h, float **dev) {
     return STCN_OK;
 }
 
-int make_f16_split(Model &m, ConvW &cw, const std::vector<float> &w) {
-    std::vector<uint16_t> hi((size_t)cw.cout * cw.Kp), lo((size_t)cw.cout * cw.Kp);
-    std::vector<float> osc(cw.cout);
-    for (int n = 0; n < cw.cout; ++n) {
-        float mx = 0.f;
-        for (int k = 0; k < cw.Kp; ++k) mx = std::max(mx, std::fabs(w[(size_t)n * cw.Kp + k]));
-        int sh = 0;
-        if (mx > 0.f) { sh = (int)std::floor(std::log2(1024.f / mx)); sh = std::min(40, std::max(-40, sh)); }
-        osc[n] = std::ldexp(1.f, -sh) / CONV_F16_ASCALE;
-        for (int k = 0; k < cw.Kp; ++k) {
-            const float v = std::ldexp(w[(size_t)n * cw.Kp + k], sh);
-            const _Float16 h = (_Float16)v;
-            const _Float16 l = (_Float16)(v - (float)h);
-            std::memcpy(&hi[(size_t)n * cw.Kp + k], &h, 2);
-            std::memcpy(&lo[(size_t)n * cw.Kp + k], &l, 2);
-        }
-    }
-    for (auto pr : {std::make_pair(&hi, &cw.w_hi), std::make_pair(&lo, &cw.w_lo)}) {
-        HIPCHK(hipMalloc((void **)pr.second, pr.first->size() * 2));
-        m.allocs.push_back(*pr.second);
-        HIPCHK(hipMemcpy(*pr.second, pr.first->data(), pr.first->size() * 2, hipMemcpyHostToDevice));
-    }
-    return upload(m, osc, &cw.oscale);
-}
-
 int make_wino(Model &m, ConvW &cw, const std::vector<float> &w) {
     static const bool on = [] { const char *e = getenv("STCN_WINOGRAD"); return !e || atoi(e) != 0; }();
-    if (!on || cw.kh != 3 || cw.kw != 3 || cw.cin_p % 32 || cw.cin_p < 128 || cw.cout % 64 || (m.precision & 1)) return STCN_OK;
+    if (!on || cw.kh != 3 || cw.kw != 3 || cw.cin_p % 32 || cw.cin_p < 128 || cw.cout % 64) return STCN_OK;
     std::vector<float> u((size_t)16 * cw.cin_p * cw.cout);
     wino_transform_weights(w.data(), cw.cout, cw.cin_p, cw.Kp, u.data());
     return upload(m, u, &cw.wino_u);
@@ -170,7 +145,6 @@ static int add_convs(Model &m, const std::map<std::string, HostT> &sd) {
         if (rc) return rc;
         rc = upload(m, bias, &cw.bias);
         if (rc) return rc;
-        if ((m.precision & 1) && cout > 1 && (rc = make_f16_split(m, cw, w))) return rc;
         if ((rc = make_wino(m, cw, w))) return rc;
         cw.bias0 = bias[0];
         m.conv[pre] = cw;
@@ -196,7 +170,6 @@ static int add_convs(Model &m, const std::map<std::string, HostT> &sd) {
                                     wt.p[(((size_t)n * cin + c) * kh + y) * kw + x] * scale[n];
                 std::vector<float> bb = part ? bias : std::vector<float>(cout, 0.f);
                 if ((rc = upload(m, ww, &pw.w)) || (rc = upload(m, bb, &pw.bias))) return rc;
-                if ((m.precision & 1) && (rc = make_f16_split(m, pw, ww))) return rc;
                 if ((rc = make_wino(m, pw, ww))) return rc;
                 pw.bias0 = bb[0];
                 m.conv[pre + (part ? "#b" : "#a")] = pw;
@@ -321,7 +294,15 @@ void Work::release() {
 // ---------------------------------------------------------------------------------------------- stages
 // a kernel launch that fails (bad configuration, LDS opt-in missing on this device ...) is reported where it happens, with
 // the launch class that failed - not as an anonymous error at the end of the interaction
+// fault injection for tests (stcn_test_fail_at): the n-th launch_status() call of this thread reports a failure
+static thread_local int g_fail_countdown = 0;
+void inject_failure_after(int n) { g_fail_countdown = n; }
 int launch_status(const char *what) {
+    if (g_fail_countdown > 0 && --g_fail_countdown == 0) {
+        (void)hipGetLastError();
+        set_error("launch of '%s' failed: injected fault (stcn_test_fail_at)", what);
+        return STCN_E_HIP;
+    }
     const hipError_t er = hipGetLastError();
     if (er == hipSuccess) return STCN_OK;
     set_error("launch of '%s' failed: %s", what, hipGetErrorString(er));
@@ -353,15 +334,14 @@ int run_conv(const Model &m, Work &w, hipStream_t s, const char *name, const flo
     p.x1_bytes = (unsigned)x1b;
     p.w_bytes = (unsigned)((long)cw.cout * cw.Kp * 4);
     if (x1 && ((cw.cin_p % 32) || (c0 % 32) || cw.kh * cw.kw > 32)) { set_error("conv '%s': two-source input needs 32-aligned channel splits", name); return STCN_E_INVALID; }
-    p.w = cw.w; p.w_hi = cw.w_hi; p.w_lo = cw.w_lo; p.oscale = cw.oscale; p.wino_u = cw.wino_u;
-    p.mode = ((m.precision & 1) && cw.w_hi) ? 1 : 0;
+    p.w = cw.w; p.wino_u = cw.wino_u;
     p.bias = cw.bias; p.res = res; p.res_bs = res_bs; p.res_bmod = res_bmod; p.y = y; p.y_bs = y_bs;
     p.relu_in = relu_in; p.relu_out = relu_out;
     p.fd_ohw = fastdiv_make((unsigned)(p.OH * p.OW));
     p.fd_ow = fastdiv_make((unsigned)p.OW);
     p.pointwise = cw.kh == 1 && cw.kw == 1 && stride == 1 && !x1 && bs0 == (long)H * W * c0;
     p.affine_out = (y_bs == 0 || y_bs == (long)p.OH * p.OW * p.N) && (!res || (res_bs == (long)p.OH * p.OW * p.N && !res_bmod)) &&
-                   ((long)p.M + 64) * p.N * 4 < (1L << 32);
+                   ((long)p.M + 128) * p.N * 4 < (1L << 32);
     p.partial = w.splitk;
     conv_plan(p, force_splitk, w.splitk_floats);
     const double fl = 2.0 * p.M * p.N * (double)(cw.kh * cw.kw * cw.cin);
@@ -378,11 +358,13 @@ int run_conv(const Model &m, Work &w, hipStream_t s, const char *name, const flo
         const double bytes = 4.0 * (in0 + in1 + (double)cw.cout * cw.K + (double)p.M * p.N + resb);
         // launches below the machine balance (157.3 TFLOP/s / 8 TB/s = 19.7 FLOP/B) are HBM-bound: accounted apart too
         const bool hbm_bound = fl / bytes < 157.3e12 / 8.0e12;
-        w.prof->bytes[STCN_K_CONV] += bytes;
-        w.prof->flops[STCN_K_CONV] += fl;
-        w.prof->exec_flops[STCN_K_CONV] += fl_exec;
-        if (hbm_bound) { w.prof->hbm_conv_bytes += bytes; w.prof->hbm_conv_flops += fl; }
-        eg = w.prof->attach(STCN_K_CONV, hbm_bound);
+        const int cls = w.conv_cls;
+        const bool hbm_acc = hbm_bound && cls == STCN_K_CONV;
+        w.prof->bytes[cls] += bytes;
+        w.prof->flops[cls] += fl;
+        w.prof->exec_flops[cls] += fl_exec;
+        if (hbm_acc) { w.prof->hbm_conv_bytes += bytes; w.prof->hbm_conv_flops += fl; }
+        eg = w.prof->attach(cls, hbm_acc);
         if (wino) {
             ei = w.prof->attach(STCN_K_WINO_INPUT);
             if (wino_plan_splitk(p, w.splitk_floats) > 1) er = w.prof->attach(STCN_K_CONV_REDUCE);
@@ -588,6 +570,7 @@ int fusion_logit(const Model &m, Work &w, hipStream_t s, const float *img4, cons
     if (!m.has_fuse) { set_error("model was built without a fusion network"); return STCN_E_STATE; }
     const Dims &d = w.d;
     { Scope sc(w.prof, STCN_K_ELEMWISE, s); pack_fusion_input_launch(img4, prev, curr, attn2, nc, nr, d.npix, w.A, s); }
+    struct Cls { Work &w; Cls(Work &w_) : w(w_) { w.conv_cls = STCN_K_FUSION_CONV; } ~Cls() { w.conv_cls = STCN_K_CONV; } } cls_guard(w);
     RC(conv1(m, w, s, "fuse.conv1.0", w.A, 12, 1, d.nh, d.nw, 1, w.B, nullptr, 0, 1));
     RC(conv1(m, w, s, "fuse.conv2.0", w.B, 32, 1, d.nh, d.nw, 1, w.C, nullptr, 0, 1));
     RC(conv1(m, w, s, "fuse.conv2.2", w.C, 32, 1, d.nh, d.nw, 1, w.D, w.B, 0, 1));
@@ -607,7 +590,7 @@ using namespace stcn;
 extern "C" {
 
 const char *stcn_last_error(void) { return stcn::get_error(); }
-const char *stcn_version(void) { return "stcn_hip 0.2 (gfx950; conv modes: fp32 MFMA, f16x3 split)"; }
+const char *stcn_version(void) { return "stcn_hip 0.3 (gfx950; exact-fp32 MFMA convs: direct implicit GEMM + Winograd)"; }
 
 int stcn_model_create(int device, const stcn_weight_desc *prop, int n_prop, const stcn_weight_desc *fuse, int n_fuse,
                       stcn_model **out) {
@@ -615,8 +598,6 @@ int stcn_model_create(int device, const stcn_weight_desc *prop, int n_prop, cons
     HIPCHK(hipSetDevice(device));
     stcn_model *mm = new stcn_model();
     mm->m.device = device;
-    const char *prec = getenv("STCN_PRECISION");
-    mm->m.precision = (prec && std::string(prec) == "f16x3") ? 1 : 0;
     const int rc = build_model(mm->m, prop, n_prop, fuse, n_fuse);
     if (rc) { stcn_model_destroy(mm); return rc; }
     *out = mm;
@@ -686,18 +667,25 @@ static int bank_reserve(stcn_engine *e, int slots) {
         set_error("bank_reserve: %d slots (%zu MB) -> %s", cap, ((size_t)e->k * rows * 512 * 4 + rows * 65 * 4) >> 20, hipGetErrorString(er));
         return STCN_E_HIP;
     }
+    // from here on a failure must release the three new buffers (callers may retry: several GB at 480p)
+    auto fail = [&](hipError_t err, const char *what) {
+        (void)hipStreamSynchronize(e->stream);              // copies into the new buffers may be in flight
+        (void)hipFree(nk); (void)hipFree(nq); (void)hipFree(nv);
+        set_error("bank_reserve: %s -> %s", what, hipGetErrorString(err));
+        return STCN_E_HIP;
+    };
     if (e->n_certain > 0) {
         const size_t crow = (size_t)e->n_certain * d.hw16, orow = (size_t)e->bank_cap * d.hw16;
-        HIPCHK(hipMemcpyAsync(nk, e->bank_k, crow * 64 * 4, hipMemcpyDeviceToDevice, e->stream));
-        HIPCHK(hipMemcpyAsync(nq, e->bank_msq, crow * 4, hipMemcpyDeviceToDevice, e->stream));
+        if ((er = hipMemcpyAsync(nk, e->bank_k, crow * 64 * 4, hipMemcpyDeviceToDevice, e->stream)) != hipSuccess) return fail(er, "copy of the certain keys");
+        if ((er = hipMemcpyAsync(nq, e->bank_msq, crow * 4, hipMemcpyDeviceToDevice, e->stream)) != hipSuccess) return fail(er, "copy of |mk|^2");
         for (int o = 0; o < e->k; ++o)
-            HIPCHK(hipMemcpyAsync(nv + o * rows * 512, e->bank_v + o * orow * 512, crow * 512 * 4,
-                                  hipMemcpyDeviceToDevice, e->stream));
+            if ((er = hipMemcpyAsync(nv + o * rows * 512, e->bank_v + o * orow * 512, crow * 512 * 4, hipMemcpyDeviceToDevice, e->stream)) != hipSuccess)
+                return fail(er, "copy of the certain values");
     }
     if (e->bank_k) {
         bank_collect_retired(e, true);                  // an older generation still pending: wait for it (rare)
-        if (!e->retire_ev) HIPCHK(hipEventCreateWithFlags(&e->retire_ev, hipEventDisableTiming));
-        HIPCHK(hipEventRecord(e->retire_ev, e->stream));
+        if (!e->retire_ev && (er = hipEventCreateWithFlags(&e->retire_ev, hipEventDisableTiming)) != hipSuccess) return fail(er, "event create");
+        if ((er = hipEventRecord(e->retire_ev, e->stream)) != hipSuccess) return fail(er, "event record");
         e->retired = {e->bank_k, e->bank_msq, e->bank_v};
     }
     e->bank_k = nk; e->bank_msq = nq; e->bank_v = nv; e->bank_cap = cap;
@@ -788,6 +776,7 @@ int stcn_engine_reset(stcn_engine *e) {
     if (!e) { set_error("stcn_engine_reset: null engine"); return STCN_E_INVALID; }
     HIPCHK(hipSetDevice(e->model->device));
     if (e->side) HIPCHK(hipStreamSynchronize(e->side));
+    e->failed.clear();
     e->interacted.clear();
     e->n_certain = 0;
     e->n_cached = 0;
@@ -837,7 +826,7 @@ static int clone_state(stcn_engine *e, const stcn_engine *src) {
     // only the occupied key-cache slots (a clone per candidate frame is the upper-bound policy's inner loop)
     HIPCHK(hipMemcpyAsync(e->cache, src->cache, (size_t)src->n_cached * e->slot_floats * 4, hipMemcpyDeviceToDevice, e->stream));
     e->slot_of = src->slot_of; e->n_cached = src->n_cached; e->vparts_ready = src->vparts_ready;
-    e->n_certain = src->n_certain; e->interacted = src->interacted;
+    e->n_certain = src->n_certain; e->interacted = src->interacted; e->failed = src->failed;
     const size_t crow = (size_t)e->n_certain * d.hw16;
     if (crow) {
         HIPCHK(hipMemcpyAsync(e->bank_k, src->bank_k, crow * 64 * 4, hipMemcpyDeviceToDevice, e->stream));
@@ -1063,7 +1052,7 @@ static int do_pass(stcn_engine *e, int idx, bool forward) {
                 const float nr = (float)std::abs(idx - t) / (float)std::abs(closest - idx);
                 const int cs = e->n_certain - 1;               // key of the current interaction
                 {
-                    Scope sc(&e->prof, STCN_K_OTHER, e->stream, 2.0 * d.hw16 * d.hw16 * 64);
+                    Scope sc(&e->prof, STCN_K_ATTENTION, e->stream, 2.0 * d.hw16 * d.hw16 * 64);
                     attention_read_launch(e->bank_k + (size_t)cs * d.hw16 * 64, e->bank_msq + (size_t)cs * d.hw16, f.k16, e->pos,
                                           e->neg, k + 1, d.h16, d.w16, w.pooled, w.amap, w.attn, AttnScratch{w.gmax, w.tau, w.cand_v}, e->stream);
                 }
@@ -1087,8 +1076,51 @@ static int do_pass(stcn_engine *e, int idx, bool forward) {
     return STCN_OK;
 }
 
+// the interaction proper; stcn_interact() below wraps it so that a failure leaves the engine in a defined state
+static int interact_run(stcn_engine *e, const float *mask_dev, int mask_channels, int idx, int scribble) {
+    const int kk = e->k + 1;
+    const Dims &d = e->d;
+    // reserve first: everything that can fail for lack of memory happens before the first mutation.  The bank must hold
+    // the certain slots (+1) and the temporary slots of the longer of the two sweeps
+    {
+        int lo = -1, hi = e->T;
+        for (int t : e->interacted) { if (t < idx && t > lo) lo = t; if (t > idx && t < hi) hi = t; }
+        const int span = std::max(hi - idx - 1, idx - lo - 1);
+        RC(bank_reserve(e, span / e->mem_freq + 1 + e->n_certain + 1));
+    }
+    e->interacted.insert(idx);
+    {
+        Scope sc(&e->prof, STCN_K_ELEMWISE, e->stream);
+        interact_mask_launch(mask_dev, mask_channels, e->H, e->W, d.nh, d.nw, e->lw, e->lh, e->prob + (size_t)idx * d.npix,
+                             (long)e->T * d.npix, kk, e->mask_pad, e->pos, e->neg, e->stream);
+    }
+    RC(launch_status("interaction mask"));
+    SlotPtrs kf;
+    RC(ensure_key(e, idx, &kf));
+    // certain memory: one slot per interaction, appended, never evicted (inference_core.py:235-240)
+    RC(bank_insert(e, e->n_certain, idx, kf, e->mask_pad + (scribble ? d.npix : 0), d.npix));
+    e->n_certain++;
+    RC(do_pass(e, idx, true));
+    RC(do_pass(e, idx, false));
+    {
+        Scope sc(&e->prof, STCN_K_ELEMWISE, e->stream);
+        argmax_launch(e->prob, kk, e->T, d.npix, e->masks, e->stream);
+    }
+    return launch_status("argmax");
+}
+
+// Failure semantics: argument errors are detected before anything is touched (the engine stays usable).  A failure inside
+// the interaction (a launch that fails, out of memory while the bank grows ...) rolls the HOST state back to what it was
+// before the call (interacted frames, certain-memory count; key-cache entries that were completed stay, they are plain
+// caches) and puts the engine into a FAILED state: prob / masks of the caller hold a partially propagated round, so every
+// further stcn_interact is refused with STCN_E_STATE until stcn_engine_reset() - never a continuation from half-updated
+// bookkeeping (the reference raises out of interact() in the same situation and leaves its tensors half-written too).
 int stcn_interact(stcn_engine *e, const float *mask_dev, int mask_channels, int idx, int scribble) {
     if (!e || !mask_dev) { set_error("stcn_interact: null arguments"); return STCN_E_INVALID; }
+    if (!e->failed.empty()) {
+        set_error("stcn_interact: the engine is in a failed state after '%s': call stcn_engine_reset() (or destroy it)", e->failed.c_str());
+        return STCN_E_STATE;
+    }
     if (idx < 0 || idx >= e->T) { set_error("stcn_interact: idx %d outside [0,%d)", idx, e->T); return STCN_E_INVALID; }
     const int k = e->k, kk = k + 1;
     // the reference broadcasts mask against prob[:, idx] ([k+1] rows): channels must be 1 or k+1;
@@ -1100,30 +1132,27 @@ int stcn_interact(stcn_engine *e, const float *mask_dev, int mask_channels, int 
     }
     HIPCHK(hipSetDevice(e->model->device));
     bank_collect_retired(e, false);
-    const Dims &d = e->d;
     e->stats = stcn_stats{};
     e->prof.reset();
-    e->interacted.insert(idx);
-    {
-        Scope sc(&e->prof, STCN_K_ELEMWISE, e->stream);
-        interact_mask_launch(mask_dev, mask_channels, e->H, e->W, d.nh, d.nw, e->lw, e->lh, e->prob + (size_t)idx * d.npix,
-                             (long)e->T * d.npix, kk, e->mask_pad, e->pos, e->neg, e->stream);
+    const bool was_interacted = e->interacted.count(idx) != 0;
+    const int n_certain0 = e->n_certain;
+    const int rc = interact_run(e, mask_dev, mask_channels, idx, scribble);
+    if (rc) {
+        const std::string why = get_error();
+        (void)hipStreamSynchronize(e->stream);              // nothing of the failed round is still in flight
+        if (e->side) (void)hipStreamSynchronize(e->side);
+        (void)hipGetLastError();
+        if (!was_interacted) e->interacted.erase(idx);
+        e->n_certain = n_certain0;
+        std::fill(e->key_pending.begin(), e->key_pending.end(), 0);     // both streams are drained
+        e->failed = why;
+        set_error("%s", why.c_str());
     }
-    SlotPtrs kf;
-    RC(ensure_key(e, idx, &kf));
-    RC(bank_reserve(e, e->n_certain + 1));
-    // certain memory: one slot per interaction, appended, never evicted (inference_core.py:235-240)
-    RC(bank_insert(e, e->n_certain, idx, kf, e->mask_pad + (scribble ? d.npix : 0), d.npix));
-    e->n_certain++;
-    RC(do_pass(e, idx, true));
-    RC(do_pass(e, idx, false));
-    {
-        Scope sc(&e->prof, STCN_K_ELEMWISE, e->stream);
-        argmax_launch(e->prob, kk, e->T, d.npix, e->masks, e->stream);
-    }
-    HIPCHK(hipGetLastError());
-    return STCN_OK;
+    return rc;
 }
+
+// test hook: the n-th launch-status check of the calling thread (counted from now) reports an injected failure
+int stcn_test_fail_at(int n) { inject_failure_after(n); return STCN_OK; }
 
 int stcn_get_stats(const stcn_engine *e, stcn_stats *out) {
     if (!e || !out) return STCN_E_INVALID;

@@ -17,8 +17,6 @@ namespace stcn {
 void set_error(const char *fmt, ...);
 struct Model;
 struct ConvW;
-// builds the fp16 hi / lo weight arrays + output scales of one conv from its repacked fp32 host weights
-int make_f16_split(Model &m, ConvW &cw, const std::vector<float> &w_host);
 // builds the Winograd weights of a stride-1-capable 3x3 conv from its repacked fp32 host weights (no-op when not eligible)
 int make_wino(Model &m, ConvW &cw, const std::vector<float> &w_host);
 #define HIPCHK(x)                                                                          \
@@ -32,8 +30,6 @@ int make_wino(Model &m, ConvW &cw, const std::vector<float> &w_host);
 
 struct ConvW {
     float *w = nullptr, *bias = nullptr;   // device: [Cout][Kp], [Cout]
-    uint16_t *w_hi = nullptr, *w_lo = nullptr;   // device: fp16 hi/lo of 2^s_n * w (f16x3 mode)
-    float *oscale = nullptr;               // device: [Cout] 2^-s_n / 4
     float *wino_u = nullptr;               // device: Winograd F(2x2,3x3) weights [16][Cin/8][Cout][8] (eligible 3x3 convs)
     float bias0 = 0.f;                     // host copy of bias[0] (Cout == 1 convs)
     int cout = 0, cin = 0, cin_p = 0, kh = 0, kw = 0, K = 0, Kp = 0;
@@ -41,7 +37,6 @@ struct ConvW {
 
 struct Model {
     int device = 0;
-    int precision = 0;                     // 0 = fp32 MFMA, 1 = f16x3 split (env STCN_PRECISION=f16x3)
     std::map<std::string, ConvW> conv;
     CbamW cbam{};
     bool has_fuse = false;
@@ -100,6 +95,7 @@ struct Work {
     float *qk = nullptr;                // [group][hw16][64] queries of a decode group
     float *vin = nullptr;               // value-encoder packed input [k][npix][8]
     Prof *prof = nullptr;
+    int conv_cls = STCN_K_CONV;         // accounting class of the conv GEMMs launched through this workspace (fusion_logit switches it)
     std::vector<void *> allocs;
     int init(int nh, int nw, int k, int key_batch = 1, int group = 1);   // group: frames decoded per pass (k == 1)
     void release();
@@ -107,6 +103,7 @@ struct Work {
 
 // ---- stages (enqueue only) -----------------------------------------------------------------
 struct KeyOut { float *k16, *msq, *f16_thin, *f16, *s8, *s4, *f8_copy, *f4_copy, *dthin = nullptr, *cthin = nullptr; };
+void inject_failure_after(int n);        // tests: the n-th launch_status() of this thread fails
 int launch_status(const char *what);     // STCN_OK, or STCN_E_HIP with the failing launch class in the error string
 int run_conv(const Model &m, Work &w, hipStream_t s, const char *name, const float *x0, int c0, long bs0,
              const float *x1, int c1, long bs1, int B, int H, int W, int stride, float *y, long y_bs,
@@ -165,5 +162,6 @@ struct stcn_engine {
     int group = 1;                       // frames per memory-read + decoder pass (env STCN_DECODE_BATCH, k == 1)
     stcn::Prof prof;
     stcn_stats stats{};
+    std::string failed;                  // non-empty: a failed interaction left prob / masks half-written (see stcn_interact)
     std::vector<void *> allocs;
 };

@@ -39,19 +39,11 @@ int stcn_test_conv(void *stream, const float *x, const float *wgt, const float *
     HIPCHK(hipMemsetAsync(wpad.p, 0, (size_t)Cout * cw.Kp * 4, s));
     HIPCHK(hipMemcpy2DAsync(wpad.p, (size_t)cw.Kp * 4, wgt, (size_t)cw.K * 4, (size_t)cw.K * 4, Cout, hipMemcpyDeviceToDevice, s));
     cw.w = wpad.p; cw.bias = const_cast<float *>(bias);
-    const char *prec = getenv("STCN_PRECISION");
-    m.precision = (prec && std::string(prec) == "f16x3" && Cout > 1) ? 1 : 0;
     struct Guard { Model &m; ~Guard() { (void)hipDeviceSynchronize(); for (void *p : m.allocs) (void)hipFree(p); } } guard{m};
-    if (m.precision == 1) {
-        HIPCHK(hipStreamSynchronize(s));
-        std::vector<float> hw((size_t)Cout * cw.Kp);
-        HIPCHK(hipMemcpy(hw.data(), wpad.p, hw.size() * 4, hipMemcpyDeviceToHost));
-        RC(make_f16_split(m, cw, hw));
-    }
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
     Work w;
     DevBuf wv;
-    if (m.precision == 0 && KH == 3 && stride == 1) {          // stride-1 3x3: the Winograd path, as in the engine
+    if (KH == 3 && stride == 1) {          // stride-1 3x3: the Winograd path, as in the engine
         HIPCHK(hipStreamSynchronize(s));
         std::vector<float> hw((size_t)Cout * cw.Kp);
         HIPCHK(hipMemcpy(hw.data(), wpad.p, hw.size() * 4, hipMemcpyDeviceToHost));
@@ -101,13 +93,10 @@ int stcn_bench_conv(void *stream, int B, int H, int W, int Cin, int Cout, int KH
     HIPCHK(hipMemcpy(wt.p, h.data(), h.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemsetAsync(b.p, 0, Cout * 4, s));
     cw.w = wt.p; cw.bias = b.p;
-    const char *prec = getenv("STCN_PRECISION");
-    m.precision = (prec && std::string(prec) == "f16x3" && Cout > 1) ? 1 : 0;
     struct Guard { Model &m; ~Guard() { (void)hipDeviceSynchronize(); for (void *p : m.allocs) (void)hipFree(p); } } guard{m};
-    if (m.precision == 1) RC(make_f16_split(m, cw, h));
     Work w;
     DevBuf wv;
-    if (m.precision == 0 && KH == 3 && stride == 1) {
+    if (KH == 3 && stride == 1) {
         RC(make_wino(m, cw, h));
         w.wino_v_floats = (size_t)16 * Cin * (((size_t)B * ((OH + 1) / 2) * ((OW + 1) / 2) + 63) / 64 * 64);
         RC(wv.alloc(w.wino_v_floats));
@@ -223,6 +212,14 @@ int stcn_bench_memory_read(void *stream, const float *mk, const float *mv, const
     return STCN_OK;
 }
 
+int stcn_memread_plan(int N, int Q, int32_t *plan7) {
+    if (!plan7 || N < 1 || Q < 1) { set_error("stcn_memread_plan: bad arguments"); return STCN_E_INVALID; }
+    const MemReadPlan pl = memread_plan(N, Q);
+    const int v[7] = {pl.steps, pl.ss, pl.ns, pl.nc1, pl.spc1, pl.nc2, pl.spc2};
+    for (int i = 0; i < 7; ++i) plan7[i] = v[i];
+    return STCN_OK;
+}
+
 int stcn_test_decode(const stcn_model *m, void *stream, const float *readout, const float *f16_thin, const float *f8,
                      const float *f4, int k, int nh, int nw, float *logit4, float *agg) {
     if (!m || !readout || !f16_thin || !f8 || !f4 || !agg) { set_error("stcn_test_decode: bad arguments"); return STCN_E_INVALID; }
@@ -270,87 +267,6 @@ int stcn_test_fusion(const stcn_model *m, void *stream, const float *img, const 
     RC(fusion_logit(m->m, t.w, s, img4.p, prev, curr, attn, nc, nr, logit));
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());
-    return STCN_OK;
-}
-
-// Overlap stress test (debug): a victim kernel (0 = merge_readout, 1 = plain gather-sum) runs `iters` times on
-// stream A into separate outputs while conv kernels of `conv_mode` (0 fp32, 1 f16x3, -1 none) run back-to-back
-// on stream B; returns how many of the victim's outputs differ from its solo result.
-int stcn_debug_overlap(int victim, int conv_mode, int iters, int *mismatching, int *first_bad_index) {
-    const int Q = 1620, N = 1620, NC = 13;
-    hipStream_t sa, sb;
-    HIPCHK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
-    DevBuf table, candv, candi, w, idx, ref, outs, cx, cw, cb, cy, cws;
-    RC(table.alloc((size_t)N * 512)); RC(candv.alloc((size_t)NC * Q * 50)); RC(candi.alloc((size_t)NC * Q * 50));
-    RC(w.alloc((size_t)Q * 50)); RC(idx.alloc((size_t)Q * 50)); RC(ref.alloc((size_t)Q * 512));
-    RC(outs.alloc((size_t)iters * Q * 512));
-    std::vector<float> h((size_t)N * 512);
-    unsigned st = 777u;
-    auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 32768.f - 1.f; };
-    for (auto &v : h) v = rnd() * 10.f;
-    HIPCHK(hipMemcpy(table.p, h.data(), h.size() * 4, hipMemcpyHostToDevice));
-    std::vector<float> hv((size_t)NC * Q * 50), hw((size_t)Q * 50);
-    std::vector<int32_t> hi((size_t)NC * Q * 50), hx((size_t)Q * 50);
-    for (size_t i = 0; i < hv.size(); ++i) { hv[i] = rnd() * 5.f; st = st * 1664525u + 1013904223u; hi[i] = (int32_t)((st >> 8) % N); }
-    for (size_t i = 0; i < hw.size(); ++i) { hw[i] = 0.02f + 0.001f * rnd(); st = st * 1664525u + 1013904223u; hx[i] = (int32_t)((st >> 8) % N); }
-    HIPCHK(hipMemcpy(candv.p, hv.data(), hv.size() * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(candi.p, hi.data(), hi.size() * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(w.p, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(idx.p, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
-    auto victim_launch = [&](float *out) {
-        if (victim == 0) merge_only_launch(candv.p, reinterpret_cast<int32_t *>(candi.p), NC, Q, table.p, 0, 1, out, 0, sa);
-        else if (victim == 1) gather_sum_launch(table.p, reinterpret_cast<int32_t *>(idx.p), w.p, Q, out, sa);
-        else gather_sum_scalar_launch(table.p, reinterpret_cast<int32_t *>(idx.p), w.p, Q, out, sa);
-    };
-    victim_launch(ref.p);
-    HIPCHK(hipStreamSynchronize(sa));
-    // conv workload on stream B
-    Model m;
-    struct Guard { Model &m; ~Guard() { (void)hipDeviceSynchronize(); for (void *p : m.allocs) (void)hipFree(p); } } guard{m};
-    Work wk;
-    const int B = 1, H = 60, W = 108, Cin = 256, Cout = 256, K = 3;
-    if (conv_mode >= 0) {
-        ConvW cv;
-        cv.cout = Cout; cv.cin = Cin; cv.cin_p = Cin; cv.kh = K; cv.kw = K; cv.K = K * K * Cin; cv.Kp = cv.K;
-        RC(cx.alloc((size_t)B * H * W * Cin)); RC(cw.alloc((size_t)Cout * cv.Kp)); RC(cb.alloc(Cout));
-        RC(cy.alloc((size_t)B * H * W * Cout)); RC(cws.alloc((size_t)8 * 1024 * 1024));
-        std::vector<float> hc((size_t)B * H * W * Cin);
-        for (auto &v : hc) v = rnd();
-        HIPCHK(hipMemcpy(cx.p, hc.data(), hc.size() * 4, hipMemcpyHostToDevice));
-        hc.assign((size_t)Cout * cv.Kp, 0.f);
-        for (auto &v : hc) v = rnd() * 0.03f;
-        HIPCHK(hipMemcpy(cw.p, hc.data(), hc.size() * 4, hipMemcpyHostToDevice));
-        HIPCHK(hipMemset(cb.p, 0, Cout * 4));
-        cv.w = cw.p; cv.bias = cb.p;
-        m.precision = conv_mode;
-        if (conv_mode & 1) RC(make_f16_split(m, cv, hc));
-        m.conv["t"] = cv;
-        wk.splitk = cws.p; wk.splitk_floats = (size_t)8 * 1024 * 1024;
-    }
-    for (int i = 0; i < iters; ++i) {
-        if (conv_mode >= 0)
-            for (int r = 0; r < 3; ++r)
-                RC(run_conv(m, wk, sb, "t", cx.p, Cin, (long)H * W * Cin, nullptr, 0, 0, B, H, W, 1, cy.p, 0, nullptr, 0, 0, 1, 0));
-        victim_launch(outs.p + (size_t)i * Q * 512);
-    }
-    HIPCHK(hipStreamSynchronize(sa));
-    HIPCHK(hipStreamSynchronize(sb));
-    std::vector<float> hr((size_t)Q * 512), ho((size_t)Q * 512);
-    HIPCHK(hipMemcpy(hr.data(), ref.p, hr.size() * 4, hipMemcpyDeviceToHost));
-    int bad = 0, first = -1;
-    for (int i = 0; i < iters; ++i) {
-        HIPCHK(hipMemcpy(ho.data(), outs.p + (size_t)i * Q * 512, ho.size() * 4, hipMemcpyDeviceToHost));
-        if (memcmp(hr.data(), ho.data(), hr.size() * 4)) {
-            ++bad;
-            if (first < 0)
-                for (size_t e = 0; e < hr.size(); ++e)
-                    if (memcmp(&hr[e], &ho[e], 4)) { first = (int)e; break; }
-        }
-    }
-    if (mismatching) *mismatching = bad;
-    if (first_bad_index) *first_bad_index = first;
-    (void)hipStreamDestroy(sa); (void)hipStreamDestroy(sb);
     return STCN_OK;
 }
 

@@ -42,9 +42,6 @@ struct ConvP {
     int M, N;               // M = B*OH*OW rows, N = Cout
     int K, Kp;              // K = KH*KW*Cin, Kp = K rounded up to 32 (weights zero-padded)
     const float *w;         // [N][Kp], k ordered (kh, kw, cin)
-    const uint16_t *w_hi, *w_lo;   // f16x3 mode: fp16 hi / lo halves of 2^s_n * w, same [N][Kp] layout
-    const float *oscale;    // f16x3 mode: per output channel 2^-s_n / 4 (undoes the operand pre-scaling)
-    int mode;               // 0 = exact fp32 MFMA, 1 = f16x3 split on the f16 MFMA pipe
     const float *bias;      // [N] or nullptr
     const float *res;       // residual [B][OH*OW][N] or nullptr
     long res_bs;            // batch stride of res (0 = broadcast)
@@ -80,9 +77,6 @@ void wino_launch(const ConvP &p, float *V, size_t slab_floats, hipStream_t s, hi
                  hipEvent_t *ev_red = nullptr);
 int wino_plan_splitk(const ConvP &p, size_t slab_floats);
 void wino_transform_weights(const float *w, int N, int Cin, int Kp, float *U);
-void conv_f16x3_launch(const ConvP &p, int tiles_n, int ntile, int per, dim3 grid, hipStream_t s, hipEvent_t e0,
-                       hipEvent_t e1);
-static constexpr float CONV_F16_ASCALE = 4.f;
 
 // Cout == 1 convolution (decoder.pred, FusionNet.final_conv): one dot product per output pixel.
 // x [B,H,W,C] (C multiple of 4), w [KH*KW*C], y [B*H*W]; stride 1, "same" padding.
@@ -162,8 +156,5 @@ void jf_counts_launch(const uint8_t *gt, const uint8_t *pred, int T, int H, int 
 // debug/stress: launch ONLY the merge stage on prepared candidate lists (cand_v/cand_i [NC][Q][50])
 void merge_only_launch(const float *cand_v, const int32_t *cand_i, int NC, int Q, const float *mv, long mv_os, int k,
                        float *readout, long ro_os, hipStream_t s);
-// debug/stress: trivial victim - out[q][c] = sum_j w[q][j] * table[idx[q][j]][c] with the same access pattern
-void gather_sum_launch(const float *table, const int32_t *idx, const float *w, int Q, float *out, hipStream_t s);
-void gather_sum_scalar_launch(const float *table, const int32_t *idx, const float *w, int Q, float *out, hipStream_t s);
 
 }  // namespace stcn

@@ -604,55 +604,6 @@ void merge_only_launch(const float *cand_v, const int32_t *cand_i, int NC, int Q
                        mv, mv_os, k, readout, ro_os, (int32_t *)nullptr, (float *)nullptr);
 }
 
-// one wave per query, no LDS: 50 rows x 2 KB gathered with 16-byte loads (same pattern as merge_readout's gather)
-__global__ __launch_bounds__(256) void gather_sum_kernel(const float *__restrict__ table, const int32_t *__restrict__ idx,
-                                                         const float *__restrict__ w, int Q, float *__restrict__ out) {
-    const int lane = threadIdx.x & 63;
-    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (q >= Q) return;
-    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 5
-    for (int j = 0; j < TOPK; ++j) {
-        const float wj = w[(long)q * TOPK + j];
-        const float *row = table + (long)idx[(long)q * TOPK + j] * 512 + 4 * lane;
-        a0 += *reinterpret_cast<const f32x4 *>(row) * wj;
-        a1 += *reinterpret_cast<const f32x4 *>(row + 256) * wj;
-    }
-    float *dst = out + (long)q * 512 + 4 * lane;
-    *reinterpret_cast<f32x4 *>(dst) = a0;
-    *reinterpret_cast<f32x4 *>(dst + 256) = a1;
-}
-// same victim with scalar FMAs only (inline asm v_fmac_f32: the compiler cannot form v_pk_fma_f32)
-__global__ __launch_bounds__(256) void gather_sum_scalar_kernel(const float *__restrict__ table,
-                                                                const int32_t *__restrict__ idx,
-                                                                const float *__restrict__ w, int Q,
-                                                                float *__restrict__ out) {
-    const int lane = threadIdx.x & 63;
-    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (q >= Q) return;
-    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll 5
-    for (int j = 0; j < TOPK; ++j) {
-        const float wj = w[(long)q * TOPK + j];
-        const float *row = table + (long)idx[(long)q * TOPK + j] * 512 + 4 * lane;
-        const f32x4 r0 = *reinterpret_cast<const f32x4 *>(row), r1 = *reinterpret_cast<const f32x4 *>(row + 256);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[c]) : "v"(r0[c]), "v"(wj));
-            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[4 + c]) : "v"(r1[c]), "v"(wj));
-        }
-    }
-    float *dst = out + (long)q * 512 + 4 * lane;
-    *reinterpret_cast<f32x4 *>(dst) = f32x4{a[0], a[1], a[2], a[3]};
-    *reinterpret_cast<f32x4 *>(dst + 256) = f32x4{a[4], a[5], a[6], a[7]};
-}
-void gather_sum_launch(const float *table, const int32_t *idx, const float *w, int Q, float *out, hipStream_t s) {
-    hipLaunchKernelGGL(gather_sum_kernel, dim3((Q + 3) / 4), dim3(256), 0, s, table, idx, w, Q, out);
-}
-void gather_sum_scalar_launch(const float *table, const int32_t *idx, const float *w, int Q, float *out, hipStream_t s) {
-    hipLaunchKernelGGL(gather_sum_scalar_kernel, dim3((Q + 3) / 4), dim3(256), 0, s, table, idx, w, Q, out);
-}
-
 // ------------------------------------------------------------------------------------------------
 // Fusion attention read (prop_net.py:117-138,198-211): W = softmax over memory rows of the T=1
 // affinity; amap[kk][ch][q] = sum_m pooled[kk][ch][m] W[m][q]; then bilinear x16.

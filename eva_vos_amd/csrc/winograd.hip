@@ -274,7 +274,7 @@ static bool wino_enabled() {
 
 // floats of V workspace the Winograd path needs for this conv (0: not eligible)
 size_t wino_workspace_floats(const ConvP &p) {
-    if (!wino_enabled() || !p.wino_u || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.x1 || (p.mode & 1)) return 0;
+    if (!wino_enabled() || !p.wino_u || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.x1) return 0;
     if (p.Cin % 32 || p.Cin < 128 || p.N % WN || p.bs0 == 0) return 0;    // 64-channel layers: the transforms cost more than they save
     const long Mt = (long)p.B * ((p.OH + 1) / 2) * ((p.OW + 1) / 2);
     const long Mt_pad = (Mt + WT - 1) / WT * WT;
@@ -336,8 +336,9 @@ void wino_launch(const ConvP &p, float *V, size_t slab_floats, hipStream_t s, hi
     const size_t lds = (size_t)16 * WT * 32 * sizeof(float);
     // 16 waves x 1 position (4 waves per SIMD) feed the matrix pipe a little better on the short-K layers (+1.5-3 % up to 512
     // input channels); with 1024+ channels the 8-wave form with its deeper per-wave prefetch is as good or better
-    static const int ppw_env = [] { const char *e = getenv("STCN_WINO_PPW"); return e ? atoi(e) : 0; }();
-    const int ppw = ppw_env ? ppw_env : (p.Cin <= 512 ? 1 : 2);
+    const char *ppw_s = getenv("STCN_WINO_PPW");          // read per launch: tests run every shape under both instances
+    const int ppw_env = ppw_s ? atoi(ppw_s) : 0;
+    const int ppw = ppw_env == 1 || ppw_env == 2 ? ppw_env : (p.Cin <= 512 ? 1 : 2);
     if (ppw == 1) {
         allow_big_lds(reinterpret_cast<const void *>(&wino_gemm_kernel<1>), lds);
         if (ev_gemm)

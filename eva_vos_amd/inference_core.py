@@ -54,17 +54,39 @@ _MODEL_LOCK = threading.Lock()
 
 
 def _fingerprint(module) -> tuple:
-    """(storage address, in-place version) of every tensor of the state_dict: changes when a checkpoint is loaded into the
-    module (load_state_dict copies in place and bumps the versions) or a parameter is replaced."""
+    """(storage address, in-place version) of every tensor of the state_dict - changes when a checkpoint is loaded into the
+    module (load_state_dict copies in place and bumps the versions) or a parameter is replaced - plus a content probe of a
+    few tensors: writes through ``p.data`` (``p.data.copy_()``, ``p.data.mul_()``) do NOT bump ``_version``; the probe
+    (sums over the first 4096 elements of 8 tensors spread over the state_dict) catches a whole-model update done that
+    way.  Limitation, by design of a snapshot: a ``.data`` write confined to tensors outside the probe is not seen - call
+    ``eva_vos_amd.inference_core.forget_models()`` after such surgery (the reference reads live parameters)."""
     if module is None:
         return ()
-    return tuple((v.data_ptr(), v._version) for v in module.state_dict(keep_vars=True).values())
+    sd = list(module.state_dict(keep_vars=True).values())
+    ids = tuple((v.data_ptr(), v._version) for v in sd)
+    fl = [v for v in sd if v.is_floating_point() and v.numel() > 0]
+    probe = []
+    for i in sorted({(len(fl) - 1) * j // 7 for j in range(8)}) if fl else ():
+        x = fl[i].detach().reshape(-1)[:4096].double()
+        probe.append((float(x.sum()), float(x.abs().sum())))
+    return ids + tuple(probe)
+
+
+_SNAPSHOTS_PER_DEVICE = 4      # LRU: alternating a few (prop_net weights, fuse_net) pairs must not re-fold the model every time
+
+
+def forget_models() -> None:
+    """Drop every cached weight snapshot (engines alive keep theirs): the next InferenceCore re-reads the modules."""
+    with _MODEL_LOCK:
+        _MODEL_CACHE.clear()
 
 
 def _model_for(prop_net, fuse_net, device_index: int) -> _Model:
     """The engine works on a BN-folded, repacked SNAPSHOT of the weights.  The reference reads the live parameters, so the
     snapshot is keyed on a fingerprint of both modules' tensors: loading another checkpoint into the same module objects
-    (one script evaluating several checkpoints) yields a fresh model; the stale one dies with its last engine."""
+    (one script evaluating several checkpoints) yields a fresh model.  A small LRU per (prop_net, device) keeps the last
+    few snapshots, so alternating two fusion networks (or fuse_net / None) does not re-upload 218 MB per construction;
+    older ones die with their last engine."""
     with _MODEL_LOCK:                       # engines may be created from several host threads (one per video)
         per_net = _MODEL_CACHE.setdefault(prop_net, {})
         key = (device_index, _fingerprint(prop_net), _fingerprint(fuse_net))
@@ -72,8 +94,11 @@ def _model_for(prop_net, fuse_net, device_index: int) -> _Model:
         # the fuse_net is held weakly and compared by identity: a new module that happens to reuse a freed one's id /
         # storage addresses must not alias its packed weights
         if hit is not None and (hit[1]() if hit[1] is not None else None) is fuse_net:
+            per_net[key] = per_net.pop(key)                         # most recently used last
             return hit[0]
-        for k in [k for k in per_net if k[0] == device_index]:      # snapshots of older weights of this module: drop
+        per_net.pop(key, None)
+        mine = [k for k in per_net if k[0] == device_index]
+        for k in mine[:max(0, len(mine) - (_SNAPSHOTS_PER_DEVICE - 1))]:     # least recently used first
             del per_net[k]
         model = _Model(prop_net, fuse_net, device_index)
         per_net[key] = (model, weakref.ref(fuse_net) if fuse_net is not None else None)

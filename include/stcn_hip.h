@@ -91,6 +91,10 @@ int stcn_engine_clone(const stcn_engine *src, float *prob_dev, uint8_t *masks_de
  *                   the reference accepts (inference_core.py:220-233).
  *   Enqueues on the engine stream and returns without synchronising; prob_dev / masks_dev are
  *   complete once the stream has drained.
+ *   Errors: bad arguments (STCN_E_INVALID) are detected before anything is touched.  A failure INSIDE the
+ *   interaction (failed launch, out of memory while the bank grows) rolls the host bookkeeping back (set of
+ *   interacted frames, certain-memory count) and puts the engine into a failed state: prob_dev / masks_dev hold
+ *   a partially propagated round, further stcn_interact calls return STCN_E_STATE until stcn_engine_reset().
  * Replaces: InferenceCore.interact (inference_core.py:209-259) incl. do_pass (:126-191) and
  * fuse_one_frame (:193-207). */
 int stcn_interact(stcn_engine *e, const float *mask_dev, int mask_channels, int idx, int scribble);
@@ -152,6 +156,15 @@ int stcn_test_fusion(const stcn_model *m, void *stream, const float *img, const 
                      const float *curr, const float *attn, float nc, float nr, int nh, int nw,
                      float *logit);
 
+/* Launch plan of the top-50 memory read for N bank rows and Q queries (what stcn_test_memory_read / the engine will run):
+ * plan7 = { 64-row steps, pass-1 sample stride, sampled steps, pass-1 chunks, steps per pass-1 chunk, pass-2 chunks,
+ * steps per pass-2 chunk }.  Lets tests assert WHICH plan (sample stride 1/2/4/8) a comparison exercised. */
+int stcn_memread_plan(int N, int Q, int32_t *plan7);
+
+/* Test hook (fault injection): the n-th kernel-launch status check made by the CALLING THREAD from now on reports a
+ * failure (n = 0 disarms).  Used to show that a failing stcn_interact leaves the engine in a defined state. */
+int stcn_test_fail_at(int n);
+
 /* Time `iters` launches of the dominant kernel (implicit-GEMM conv) on `stream` with HIP events;
  * returns average milliseconds per launch.  Used by bench.py for the roofline object. */
 int stcn_bench_conv(void *stream, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
@@ -160,7 +173,8 @@ int stcn_bench_conv(void *stream, int B, int H, int W, int Cin, int Cout, int KH
 /* Per-kernel-class time of the last interact() measured with HIP events on the engine stream
  * (enabled by stcn_engine_set_profiling(e,1); adds a few % overhead).  ms[] indexed by STCN_K_*. */
 enum { STCN_K_CONV = 0, STCN_K_CONV_REDUCE, STCN_K_MEMREAD, STCN_K_ELEMWISE, STCN_K_CONV_N1,
-       STCN_K_OTHER, STCN_K_WINO_INPUT /* Winograd input transform of the 3x3 convs */, STCN_K_COUNT };
+       STCN_K_OTHER, STCN_K_WINO_INPUT /* Winograd input transform of the 3x3 convs */,
+       STCN_K_FUSION_CONV /* the FusionNet conv GEMMs (rounds >= 2) */, STCN_K_ATTENTION /* fusion attention read */, STCN_K_COUNT };
 int stcn_engine_set_profiling(stcn_engine *e, int on);
 int stcn_get_kernel_ms(const stcn_engine *e, float *ms /*[STCN_K_COUNT]*/, int32_t *launches /*[STCN_K_COUNT]*/);
 /* Algorithmic FLOP (2 x MAC) issued per kernel class by the last interact(). */
@@ -174,11 +188,6 @@ int stcn_get_kernel_exec_flops(const stcn_engine *e, double *flops /*[STCN_K_COU
  * machine balance 157.3 TFLOP/s / 8 TB/s = 19.7 FLOP/B - HBM-bound, e.g. the 1x1 channel expansions of the key encoder.
  * They are part of the STCN_K_CONV totals; out[4] = { FLOP, bytes, device ms (profiling on), launches }. */
 int stcn_get_conv_regimes(stcn_engine *e, double *out /*[4]*/);
-
-/* Debug stress test: victim kernel (0 = memory-read merge stage, 1 = plain gather-sum) on one stream, conv kernels
- * (conv_mode 0 = fp32, 1 = f16x3, -1 = none) on another, `iters` overlapped repetitions; reports how many victim
- * outputs differ from the solo result and the first differing element index. */
-int stcn_debug_overlap(int victim, int conv_mode, int iters, int *mismatching, int *first_bad_index);
 
 /* ---- caller-side metric -------------------------------------------------------
  * Integer counts behind J (region IoU) and F (boundary measure) for T frames, on the device.

@@ -156,15 +156,16 @@ def fusion_case(tag, H, W, fus, fsd, out):
     return {"fusion": dmax(ref, o)}
 
 
-def self_noise(tag, H, W, k, T, mem_freq, script, net, fus, **_):
+def self_noise(tag, H, W, k, T, mem_freq, script, net, fus, threads=(1, 2, 4, 8), **_):
     """Noise floor of the REFERENCE ITSELF: the same sequence run with 1, 2, 4 and 8 intra-op threads (different fp32
     summation orders inside the CPU kernels) - four equally valid executions of the reference.  Returns per round the
-    WORST over the six pairs of: per-object (1 - IoU), max and p99.9 |prob| difference, differing mask pixels.  Tests
-    bound an implementation's mask difference from the golden by max(1e-3, this envelope)."""
+    WORST over the six pairs of: per-object (1 - IoU) over the whole clip, max and p99.9 |prob| difference, differing mask
+    pixels, and (column 4) the worst PER-FRAME per-object (1 - IoU) over the frames where the object has >= 64 pixels.  Tests
+    bound an implementation's mask difference from the golden by max(1e-3, 3 x this envelope)."""
     img = synth.synthetic_clip(T, H, W)
     msk = synth.synthetic_mask(T, H, W, k)
     runs = []
-    for nt in (1, 2, 4, 8):
+    for nt in threads:
         torch.set_num_threads(nt)
         ref = RefCore(net, fus, img, k, mem_freq=mem_freq, device="cpu")
         res = []
@@ -176,7 +177,7 @@ def self_noise(tag, H, W, k, T, mem_freq, script, net, fus, **_):
             res.append((rm.copy(), ref.prob.clone()))
         runs.append(res)
     torch.set_num_threads(8)
-    rows = np.zeros((len(script), 4), np.float64)
+    rows = np.zeros((len(script), 5), np.float64)
     for i in range(len(runs)):
         for j in range(i + 1, len(runs)):
             for r, ((m1, p1), (m8, p8)) in enumerate(zip(runs[i], runs[j])):
@@ -186,12 +187,22 @@ def self_noise(tag, H, W, k, T, mem_freq, script, net, fus, **_):
                     u = (a | b).sum()
                     worst = max(worst, 0.0 if u == 0 else 1.0 - float((a & b).sum() / u))
                 d = (p1 - p8).abs()
-                rows[r] = np.maximum(rows[r], [worst, float(d.max()), float(torch.quantile(d.flatten()[::7], 0.999)), float((m1 != m8).sum())])
+                wf = 0.0
+                for o in range(1, k + 1):
+                    a, b = (m1 == o).reshape(T, -1), (m8 == o).reshape(T, -1)
+                    u, n = (a | b).sum(1), (a & b).sum(1)
+                    ok = u >= 64
+                    if ok.any():
+                        wf = max(wf, float((1.0 - n[ok] / u[ok]).max()))
+                rows[r] = np.maximum(rows[r], [worst, float(d.max()), float(torch.quantile(d.flatten()[::7], 0.999)), float((m1 != m8).sum()), wf])
     return rows
 
 
-def seq_case(tag, H, W, k, T, mem_freq, script, net, fus, psd, fsd, out, prob_stride=2):
-    """script: list of (frame_idx_for_mask, idx) interactions."""
+def seq_case(tag, H, W, k, T, mem_freq, script, net, fus, psd, fsd, out, prob_stride=2, seed=0, decisive_eps=0.0, **_):
+    """script: list of (frame_idx_for_mask, idx) interactions.  seed: weight-recipe seed (inputs are always the seed-0 clip)."""
+    if seed:
+        net, fus, psd, fsd = load_reference(seed)
+        out[f"{tag}.seed"] = np.array(seed)
     img = synth.synthetic_clip(T, H, W)
     msk = synth.synthetic_mask(T, H, W, k)
     scribble = k > 1
@@ -209,6 +220,19 @@ def seq_case(tag, H, W, k, T, mem_freq, script, net, fus, psd, fsd, out, prob_st
         put(out, f"{tag}.r{r}.prob", ref.prob, stride=97)
         rep[f"r{r}.prob"] = dmax(ref.prob, orc.prob)
         rep[f"r{r}.mask_mismatch"] = int((rm != om).sum())
+        if decisive_eps > 0:
+            # pixels whose label is well-conditioned in the REFERENCE's own probabilities (top-1 minus top-2 >= eps), packed
+            # bits over the unpadded [T,H,W]: with several objects a random-weight decoder leaves whole regions at p ~ 1/(k+1)
+            # for every row, where the argmax is decided by the last ulp and no two executions agree (not even two thread
+            # counts of the reference: selfnoise).  Mask parity is stated on these pixels; probabilities everywhere.
+            lw, uw, lh, uh = ref.pad
+            pr = ref.prob[:, :, 0, lh:ref.prob.shape[3] - uh if uh else None, lw:ref.prob.shape[4] - uw if uw else None]
+            top = torch.topk(pr, 2, dim=0).values
+            dec = (top[0] - top[1]) >= decisive_eps
+            out[f"{tag}.r{r}.decisive"] = np.packbits(dec.numpy(), axis=None)
+            out[f"{tag}.decisive_eps"] = np.array(decisive_eps)
+            rep[f"r{r}.decisive_frac"] = float(dec.float().mean())
+            rep[f"r{r}.mask_mismatch_decisive"] = int(((rm != om) & dec.numpy()).sum())
     out[f"{tag}.trace"] = np.array([[t["idx"], int(t["forward"]), t["frames"], t["bank"], int(t["fuse"])]
                                      for t in orc.trace])
     out[f"{tag}.shape"] = np.array([T, H, W, k, mem_freq])
@@ -224,11 +248,16 @@ SEQ_CASES = {
     "seqC": dict(H=128, W=160, k=3, T=8, mem_freq=2, script=[(0, 0), (5, 5)]),
     # config-3-shaped: 5 objects, every frame enters the bank, ragged size (pads 4/4 and 3/3)
     "seqD": dict(H=120, W=170, k=5, T=7, mem_freq=1, script=[(0, 0), (4, 4)]),
+    # the seqA script under ANOTHER weight recipe (seed 1): shows that no tolerance of the suite is tuned to the seed-0 draw
+    "seqA1": dict(H=128, W=160, k=1, T=12, mem_freq=5, script=[(0, 0), (8, 8), (7, 8)], seed=1),
 }
 # BASELINE resolution end to end from the reference: 6 frames 480x854 (padded to 864), interact(0) then interact(4) with
 # fusion on frames 1..3; packed masks + every 4th prob sample as fp16 (< 1 MB).  ~1.6 s per frame and network pass here.
 FULL_CASES = {
     "seq480": dict(H=480, W=854, k=1, T=6, mem_freq=2, script=[(0, 0), (4, 4)], prob_stride=4),
+    # BASELINE config 3 shape from the reference: 5 objects through the scribble / (k+1)-channel path, every frame enters the
+    # bank (mem_freq = 1), 12 frames 480x854; uint8 masks + every 8th prob sample as fp16.  Self-noise on 2 / 4 / 8 threads.
+    "seq480k5": dict(H=480, W=854, k=5, T=12, mem_freq=1, script=[(0, 0)], prob_stride=8, threads=(2, 4, 8), decisive_eps=1e-3),
 }
 STAGE_CASES = {
     "stA": dict(H=128, W=160, k=1),
@@ -241,12 +270,16 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     net, fus, psd, fsd = load_reference()
     only = [a.split("=")[1] for a in sys.argv if a.startswith("--only=")]      # e.g. --only=seqD: just that fixture
-    if "--selfnoise" in sys.argv:     # reference-vs-reference (1 vs 8 threads) floors of every sequence fixture
-        out = {}
+    if "--selfnoise" in sys.argv:     # reference-vs-reference (1 / 2 / 4 / 8 threads) floors of the sequence fixtures
+        path = os.path.join(GOLD, "selfnoise.npz")         # --only=<tag>: (re)compute those rows, keep the others
+        out = dict(np.load(path)) if only and os.path.exists(path) else {}
         for tag, c in {**SEQ_CASES, **FULL_CASES}.items():
-            out[tag] = self_noise(tag, net=net, fus=fus, **c)
-            print("selfnoise", tag, out[tag].tolist())
-        np.savez_compressed(os.path.join(GOLD, "selfnoise.npz"), **out)
+            if only and tag not in only:
+                continue
+            n, f = (net, fus) if not c.get("seed") else load_reference(c["seed"])[:2]
+            out[tag] = self_noise(tag, net=n, fus=f, **c)
+            print("selfnoise", tag, out[tag].tolist(), flush=True)
+        np.savez_compressed(path, **out)
         return
     if only:
         for tag in only:

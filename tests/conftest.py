@@ -63,3 +63,21 @@ def iou(a, b):
     a, b = np.asarray(a).astype(bool), np.asarray(b).astype(bool)
     u = (a | b).sum()
     return 1.0 if u == 0 else float((a & b).sum() / u)
+
+
+def frame_miss(a, b, min_union=64):
+    """Worst PER-FRAME (1 - IoU) of two boolean [T,H,W] masks over the frames whose union has >= min_union pixels (a volume IoU
+    over the clip hides one bad frame among many), and the frame it occurs on."""
+    a, b = np.asarray(a).astype(bool).reshape(len(a), -1), np.asarray(b).astype(bool).reshape(len(b), -1)
+    u, n = (a | b).sum(1), (a & b).sum(1)
+    ok = u >= min_union
+    if not ok.any():
+        return 0.0, -1
+    miss = np.where(ok, 1.0 - n / np.maximum(u, 1), 0.0)
+    return float(miss.max()), int(miss.argmax())
+
+
+def frame_bound(noise_col4, union_px):
+    """Per-frame mask bound: the north_star 1e-3, or 3 x the reference's own worst per-frame difference between its 1/2/4/8-
+    thread runs on that fixture (tests/golden/selfnoise.npz, column 4), or - small objects - two pixels, whichever is larger."""
+    return max(1e-3, 3.0 * float(noise_col4), 2.0 / max(float(union_px), 1.0))

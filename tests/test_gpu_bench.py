@@ -14,7 +14,7 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 SMALL = ["--steps", "2", "--warmup", "0", "--frames", "12", "--height", "240", "--width", "432", "--streams", "1",
-         "--no-profile", "--no-f16x3-leg", "--no-r2", "--cpu-frames", "0", "--no-config3", "--no-memread-roofline"]
+         "--no-profile", "--no-r2", "--cpu-frames", "0", "--no-config3", "--no-memread-roofline", "--no-davis-val"]
 
 
 def run_bench(args, env_extra=None):
@@ -45,6 +45,28 @@ def test_gpus_flag_launches_that_many_ranks():
     assert abs(frames - 2 * 2 * 11) < 1e-6 * frames + 1e-3
     assert two["cpu_baseline"] is None and "rank 0 at N=1" in two["cpu_baseline_note"]
     assert two["concurrent_videos_bit_identical"]
+
+
+def test_davis_val_workload_is_sharded_by_lpt_over_the_ranks():
+    """--workload davis-val: the whole job runs --steps samples with the DAVIS-2017-val lengths (clamped here so that the
+    test stays small), assigned to the ranks by LPT; fixed total work -> "strong"; every sample is processed exactly once."""
+    args = [a for a in SMALL if a != "--no-davis-val"]
+    args[args.index("--steps") + 1] = "7"
+    args[args.index("--streams") + 1] = "2"
+    args += ["--workload", "davis-val", "--davis-max-frames", "9"]
+    lens = [min(t, 9) for t in [69, 50, 80, 84, 90, 75, 40]]
+    one = run_bench(["--gpus", "1"] + args)
+    dv = one["davis_val"]
+    assert one["scaling"] == "strong" and one["steps"] == 7 and dv["samples"] == 7
+    assert dv["frames_total"] == sum(t - 1 for t in lens) and dv["rank_samples"] == [7]
+    assert abs(one["value"] - dv["frames_per_s"]) < 1e-9
+    two = run_bench(["--gpus", "2"] + args, {"STCN_BENCH_DEVICE": "0", "STCN_BENCH_BACKEND": "gloo"})
+    dv = two["davis_val"]
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong"
+    assert dv["frames_total"] == sum(t - 1 for t in lens), "every sample exactly once over the two ranks"
+    assert sorted(dv["rank_samples"]) == [3, 4] and len(dv["rank_seconds"]) == 2
+    assert sorted(sum(dv["lengths_by_rank"], [])) == sorted(lens)
+    assert max(dv["rank_busy_fraction"]) == 1.0 and dv["imbalance_max_over_mean_frames"] < 1.2
 
 
 def test_real_data_hook_is_taken_when_checkpoints_and_clips_exist(tmp_path):

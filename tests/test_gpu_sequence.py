@@ -6,10 +6,10 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import iou, load_golden
+from conftest import frame_bound, frame_miss, iou, load_golden
 from eva_vos_amd import synth
 from oracle import stcn_oracle as O
-from test_oracle_golden import check_sequence_against_golden, run_sequence, tie_summary
+from test_oracle_golden import check_sequence_against_golden, run_sequence, tie_summary, weights_of
 
 pytestmark = pytest.mark.gpu
 
@@ -35,9 +35,43 @@ def clean_frame_check(core_prob, orc, rounds_done, tag):
     return len(clean)
 
 
-@pytest.mark.parametrize("tag", ["seqA", "seqB", "seqC", "seqD", "seq480"])
+def masks_close(a, b, k, tag, yard=None):
+    """HIP masks a against oracle masks b ([T,H,W] uint8): per object the clip IoU and the worst frame.  `yard` = a selfnoise
+    row of the nearest reference fixture (volume envelope, ..., per-frame envelope) or None (k = 1: the north_star 1e-3)."""
+    for o in range(1, k + 1):
+        vol = 1 - iou(a == o, b == o)
+        miss, fr = frame_miss(a == o, b == o)
+        px = ((a[fr] == o) | (b[fr] == o)).sum() if fr >= 0 else 1
+        vb = max(1e-3, 3 * float(yard[0])) if yard is not None else 1e-3
+        fb = frame_bound(yard[4] if yard is not None else 0.0, px)
+        print(f"HIP vs oracle {tag} object {o}: clip 1-IoU {vol:.2e} (bound {vb:.1e}), worst frame {fr}: {miss:.2e} (bound {fb:.1e})")
+        assert vol <= vb and miss <= fb, (tag, o, vol, vb, fr, miss, fb)
+
+
+def small_multi_object_yardstick():
+    """Reference-vs-reference envelope for k > 1 on small frames: the worst row of the seqC (k = 3, 128x160) and seqD (k = 5,
+    120x170) fixtures - the aggregation is ill-conditioned where objects saturate, whatever the frame content."""
+    n = load_golden("selfnoise")
+    return np.maximum(n["seqC"].max(0), n["seqD"].max(0))
+
+
+def nets_of(g, tag, nets, weights):
+    w = weights_of(g, tag, weights)
+    if w is weights:
+        return nets, w
+    from eva_vos_amd.params import FusionNet, PropagationNetwork
+    p, f = PropagationNetwork(), FusionNet()
+    p.load_state_dict(w[0], strict=True)
+    f.load_state_dict(w[1], strict=True)
+    return (p.eval(), f.eval()), w
+
+
+@pytest.mark.parametrize("tag", ["seqA", "seqA1", "seqB", "seqC", "seqD", "seq480", "seq480k5"])
 def test_sequences_match_reference_goldens(tag, nets, weights):
+    """seqA1 = the seqA script under weight recipe seed 1, seq480k5 = BASELINE config 3's shape (480x854, 5 objects, every
+    frame enters the bank) - all held to the SAME statements and tolerances as the seed-0 / single-object fixtures."""
     g = load_golden(tag)
+    nets, weights = nets_of(g, tag, nets, weights)
     outs = run_sequence(make_core(nets), tag, g)
     orcs = []
 
@@ -81,14 +115,14 @@ def test_oracle_parity_at_ragged_size_and_deepcopy(nets, weights):
     orc = O.OracleCore(weights[0], weights[1], img, 1, mem_freq=2)
     a, b = core.interact(msk[:, 2], 2), orc.interact(msk[:, 2], 2)
     assert a.shape == (T, H, W) and a.dtype == np.uint8
-    assert iou(a > 0, b > 0) >= 1 - 1e-3
+    masks_close(a, b, 1, "104x170 r0")
     assert tuple(core.pad) == tuple(orc.pad) and core.prob.shape == orc.prob.shape
-    d = (core.prob.cpu() - orc.prob).abs().numpy()
-    assert np.quantile(d, 0.999) < 2e-3
+    clean_frame_check(core.prob.cpu(), orc, 0, "104x170")         # max-norm on the frames before the first near-tie
     twin = copy.deepcopy(core)
     a2 = twin.interact(msk[:, 5], 5)
     b2 = orc.interact(msk[:, 5], 5)
-    assert iou(a2 > 0, b2 > 0) >= 1 - 1e-3
+    masks_close(a2, b2, 1, "104x170 r1")
+    clean_frame_check(twin.prob.cpu(), orc, 1, "104x170")
     assert np.array_equal(core.np_masks, a), "deepcopy must not alias the original's results"
     assert (core.prob.cpu() - twin.prob.cpu()).abs().max() > 1e-3
     a3 = core.interact(msk[:, 5], 5)          # the original, same second interaction -> same answer
@@ -149,7 +183,7 @@ def test_full_resolution_two_rounds_match_the_oracle(nets, weights):
     n_clean = 0
     for r, idx in enumerate((0, 5)):
         a, b = core.interact(msk[:, idx], idx), orc.interact(msk[:, idx], idx)
-        assert iou(a > 0, b > 0) >= 1 - 1e-3, idx
+        masks_close(a, b, 1, f"480x854 r{r}", yard=load_golden("selfnoise")["seq480"][r])
         n_clean += clean_frame_check(core.prob.cpu(), orc, r, "480x854")
         d = (core.prob.cpu() - orc.prob).abs().numpy()
         q = [float(np.quantile(d, v)) for v in (0.5, 0.99, 0.999)]
@@ -191,23 +225,6 @@ def test_config3_multi_object_full_bank_properties(nets, T, k):
     assert all((outs[0][0][1:] == o).mean() > 0.01 for o in range(1, k + 1))
 
 
-@pytest.mark.parametrize("tag", ["seqA", "seqC"])
-def test_f16x3_mode_matches_reference_goldens(tag, weights, monkeypatch):
-    """Opt-in f16x3 conv mode (fp16 hi/lo split on the f16 MFMA pipe, fp32 accumulation, serial execution):
-    held to the SAME tolerances as the exact-fp32 default."""
-    from eva_vos_amd.params import FusionNet, PropagationNetwork
-    monkeypatch.setenv("STCN_PRECISION", "f16x3")
-    p, f = PropagationNetwork(), FusionNet()          # fresh containers -> a fresh model handle in f16x3 mode
-    p.load_state_dict(weights[0])
-    f.load_state_dict(weights[1])
-    g = load_golden(tag)
-    outs = run_sequence(make_core((p.eval(), f.eval())), tag, g)
-    check_sequence_against_golden(outs, tag, g, prob_atol=3e-3)
-    # and it is deterministic
-    outs2 = run_sequence(make_core((p, f)), tag, g)
-    assert all(np.array_equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(outs, outs2))
-
-
 def test_long_clip_exercises_cache_flush_policy(nets, weights):
     """T = 112 > 106 cache slots: the reference flushes its key cache when it holds more than 105 frames
     (inference_core.py:118-119); the engine mirrors that (and disables key look-ahead).  Round 2 then has
@@ -220,14 +237,15 @@ def test_long_clip_exercises_cache_flush_policy(nets, weights):
     a, b = core.interact(msk[:, 0], 0), orc.interact(msk[:, 0], 0)
     s1 = core.stats()
     assert s1["key_miss"] == T and s1["frames"] == T - 1
-    assert iou(a > 0, b > 0) >= 1 - 1e-3
+    masks_close(a, b, 1, "T=112 r0")
+    n_clean = clean_frame_check(core.prob.cpu(), orc, 0, "T=112")
     a2, b2 = core.interact(msk[:, 60], 60), orc.interact(msk[:, 60], 60)
     s2 = core.stats()
     assert s2["key_miss"] > 0, "after a flush some frames must be re-encoded"
     assert s2["fused"] == 59 and s2["frames"] == T - 2
-    assert iou(a2 > 0, b2 > 0) >= 1 - 1e-3
-    d = (core.prob.cpu() - orc.prob).abs().numpy()
-    assert np.quantile(d, 0.999) < 3e-3
+    masks_close(a2, b2, 1, "T=112 r1")
+    n_clean += clean_frame_check(core.prob.cpu(), orc, 1, "T=112")
+    assert n_clean > 0, "no frame of either round precedes the first near-tie: the max-norm statement is vacuous"
 
 
 @pytest.mark.parametrize("lookahead", ["0", "2"])
@@ -320,10 +338,13 @@ def test_edge_shapes_match_oracle(T, idx, k, mf, nets, weights):
     orc = O.OracleCore(weights[0], weights[1], img, k, mem_freq=mf)
     a, b = core.interact(m, idx, scribble=k > 1), orc.interact(m, idx, scribble=k > 1)
     assert a.shape == b.shape == (T, H, W)
-    for o in range(1, k + 1):
-        assert iou(a == o, b == o) >= 1 - 5e-3
-    d = (core.prob.cpu() - orc.prob).abs().numpy()
-    assert np.quantile(d, 0.999) < 3e-3
+    yard = small_multi_object_yardstick() if k > 1 else None
+    masks_close(a, b, k, f"edge T={T} k={k}", yard=yard)
+    if k == 1:
+        clean_frame_check(core.prob.cpu(), orc, 0, f"edge T={T}")
+    elif T > 1:       # k > 1: the tail against the reference's own tail on the small multi-object fixtures (as the goldens)
+        d = (core.prob.cpu() - orc.prob).abs().numpy()
+        assert np.quantile(d, 0.999) <= 3 * yard[2] + 5e-4, (float(np.quantile(d, 0.999)), float(yard[2]))
     s = core.stats()
     assert s["frames"] == T - 1 and s["fused"] == 0
 
@@ -469,3 +490,55 @@ def test_eight_objects_is_the_engine_maximum_and_works(nets):
     assert set(np.unique(outs[0][0])) <= set(range(k + 1))
     with pytest.raises(RuntimeError, match="1<=k<=8"):
         make_core(nets)(img, 9, 3)
+
+
+def test_a_failing_interaction_leaves_a_defined_state(nets):
+    """Fault injection (stcn_test_fail_at: the n-th launch check of this thread fails): an interaction that fails midway
+    raises, rolls the host bookkeeping back and puts the engine into a failed state - the next interact is REFUSED (never a
+    continuation from a half-updated bank / interaction set) until reset(), after which the engine equals a fresh one."""
+    from eva_vos_amd import _lib
+    T, H, W = 9, 112, 144
+    img, msk = synth.synthetic_clip(T, H, W, seed=13), synth.synthetic_mask(T, H, W, 1, seed=14)
+    ref = make_core(nets)(img, 1, 3)
+    want1 = ref.interact(msk[:, 2], 2).copy()
+    want2 = ref.interact(msk[:, 6], 6).copy()
+    prob2 = ref.prob.clone()
+    for n in (1, 3, 40, 110):                  # at the first launch, in the certain-memory value encode, in either sweep
+        core = make_core(nets)(img, 1, 3)
+        assert np.array_equal(core.interact(msk[:, 2], 2), want1)
+        _lib.check(_lib.lib().stcn_test_fail_at(n))
+        try:
+            with pytest.raises(RuntimeError, match="injected fault"):
+                core.interact(msk[:, 6], 6)
+        finally:
+            _lib.check(_lib.lib().stcn_test_fail_at(0))
+        assert core.interacted == {2}, "the shim must not record a failed interaction"
+        with pytest.raises(RuntimeError, match="failed state"):
+            core.interact(msk[:, 6], 6)
+        with pytest.raises(RuntimeError, match="failed state"):
+            copy.deepcopy(core).interact(msk[:, 6], 6)           # a clone of a failed engine is failed too
+        core.reset()
+        assert np.array_equal(core.interact(msk[:, 2], 2), want1)
+        assert np.array_equal(core.interact(msk[:, 6], 6), want2) and torch.equal(core.prob, prob2)
+    # an argument error is not a failure of the engine: it stays usable
+    core = make_core(nets)(img, 1, 3)
+    with pytest.raises(RuntimeError):
+        core.interact(msk[:, 2], T + 3)
+    assert np.array_equal(core.interact(msk[:, 2], 2), want1)
+
+
+def test_weight_snapshots_are_kept_per_fusion_net_and_data_writes_are_seen(weights):
+    """Advisor items of round 2: (i) alternating two fusion networks with one propagation network must not rebuild the
+    model every time (small LRU of snapshots); (ii) a whole-model update through ``.data`` (no version bump) is caught by
+    the content probe of the fingerprint."""
+    from eva_vos_amd import inference_core as IC
+    from eva_vos_amd.params import FusionNet, PropagationNetwork
+    p, f1, f2 = PropagationNetwork(), FusionNet(), FusionNet()
+    p.load_state_dict(weights[0]); f1.load_state_dict(weights[1]); f2.load_state_dict(weights[1])
+    m1, m2, m0 = IC._model_for(p, f1, 0), IC._model_for(p, f2, 0), IC._model_for(p, None, 0)
+    assert IC._model_for(p, f1, 0) is m1 and IC._model_for(p, f2, 0) is m2 and IC._model_for(p, None, 0) is m0
+    with torch.no_grad():
+        for t in p.state_dict(keep_vars=True).values():
+            if t.is_floating_point():
+                t.data.mul_(1.0009765625)                       # exact in fp32, invisible to _version
+    assert IC._model_for(p, f1, 0) is not m1, "a .data update of every tensor must yield a fresh snapshot"

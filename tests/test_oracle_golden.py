@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import iou, load_golden, rel_err, sample_of
+from conftest import frame_bound, frame_miss, iou, load_golden, rel_err, sample_of
 from eva_vos_amd import synth
 from oracle import stcn_oracle as O
 
@@ -72,6 +72,15 @@ def test_fusion_net_matches_reference(tag, weights):
     assert np.abs(sample_of(out, 13) - g[f"{tag}.fusion_logit.sample"]).max() < 1e-4
 
 
+def weights_of(g, tag, weights):
+    """Recipe weights of a fixture: seed 0 (the session fixture) unless the fixture names another seed (seqA1: seed 1)."""
+    seed = int(g[f"{tag}.seed"]) if f"{tag}.seed" in g else 0
+    if seed == 0:
+        return weights
+    from eva_vos_amd.params import FusionNet, PropagationNetwork
+    return synth.recipe_state_dict(PropagationNetwork(), seed), synth.recipe_state_dict(FusionNet(), seed)
+
+
 def run_sequence(core_factory, tag, g):
     T, H, W, k, mem_freq = [int(v) for v in g[f"{tag}.shape"]]
     img = synth.synthetic_clip(T, H, W)
@@ -121,12 +130,37 @@ def check_sequence_against_golden(outs, tag, g, prob_atol, min_iou=1 - 1e-3, tie
         the p99.9 tail is held to 3 x the reference's own tail on that round (selfnoise.npz), not to a blanket constant."""
     T, H, W, k, _ = [int(v) for v in g[f"{tag}.shape"]]
     st = int(g[f"{tag}.prob_stride"]) if f"{tag}.prob_stride" in g else 2
-    noise = load_golden("selfnoise")[tag] if k > 1 else None
+    noise = load_golden("selfnoise")[tag]
     for r, (masks, prob) in enumerate(outs):
         ref_masks = g[f"{tag}.r{r}.masks"]
         if k == 1:
             ref_masks = np.unpackbits(ref_masks)[: T * H * W].reshape(T, H, W)
+        # Fixtures with a `decisive` bitmask (seq480k5): the pixels whose label is well-conditioned in the REFERENCE's own
+        # probabilities (top-1 minus top-2 >= 1e-3).  With 5 objects the random-recipe decoder leaves half of the frame at
+        # p ~ 1/(k+1) in every row; there the argmax hangs on the last ulp (the reference's own thread counts disagree on 4297
+        # pixels, two correct fp32 implementations with different rounding - BN folded or not - on ~2e4), so mask parity is
+        # stated on the decisive pixels, at the north_star bound, and the probabilities are compared everywhere below.
+        dec = None
+        if f"{tag}.r{r}.decisive" in g:
+            dec = np.unpackbits(g[f"{tag}.r{r}.decisive"])[: T * H * W].reshape(T, H, W).astype(bool)
+            print(f"{who} vs golden {tag} r{r}: {100 * dec.mean():.1f} % of the pixels decisive (eps {float(g[f'{tag}.decisive_eps']):.0e}); "
+                  f"mask pixels differing: {int((masks != ref_masks).sum())} in all, {int(((masks != ref_masks) & dec).sum())} on decisive pixels")
+        # (1b) per FRAME and object (a volume IoU hides one bad frame among many): 1e-3, or 3 x the reference's own worst
+        # per-frame difference between its thread counts on this round (selfnoise column 4), or two pixels
+        for o in range(1, k + 1):
+            ma, mb = masks == o, ref_masks == o
+            if dec is not None:
+                ma, mb = ma & dec, mb & dec
+            miss, fr = frame_miss(ma, mb)
+            px = (ma[fr] | mb[fr]).sum() if fr >= 0 else 1
+            fb = frame_bound(0.0 if dec is not None else noise[r][4], px)
+            print(f"{who} vs golden {tag} r{r} object {o}: worst frame {fr} 1-IoU {miss:.2e} (bound {fb:.2e})")
+            assert miss <= fb, (tag, r, o, fr, miss, fb)
+        if k == 1:
             assert iou(masks > 0, ref_masks > 0) >= min_iou, (tag, r)
+        elif dec is not None:
+            for o in range(1, k + 1):
+                assert iou((masks == o) & dec, (ref_masks == o) & dec) >= min_iou, (tag, r, o)
         else:
             # selfnoise = worst pair of the reference against ITSELF (1 / 2 / 4 / 8 threads) on this sequence.  With k > 1 the
             # aggregation is ill-conditioned where two objects saturate (p = 1 - 1e-7 after the clamp of aggregate.py:27: the
@@ -164,9 +198,10 @@ def check_sequence_against_golden(outs, tag, g, prob_atol, min_iou=1 - 1e-3, tie
         assert q999 <= tail, (tag, r, q999, tail)
 
 
-@pytest.mark.parametrize("tag", ["seqA", "seqB", "seqC", "seqD", "seq480"])
+@pytest.mark.parametrize("tag", ["seqA", "seqA1", "seqB", "seqC", "seqD", "seq480", "seq480k5"])
 def test_sequence_matches_reference(tag, weights):
     g = load_golden(tag)
+    weights = weights_of(g, tag, weights)
     cores = []
 
     def factory(img, k, mf):

@@ -52,7 +52,7 @@ wi_ns = sum(float(r["TotalDurationNs"]) for r in wi)
 rd_ns = sum(float(r["TotalDurationNs"]) for r in stats if "conv_reduce" in r["Name"])
 lines = [f"# rocprofv3 --kernel-trace --stats - {tag}, final engine of the round (solo launches)", "",
          "Command (GPU box): `cd /tmp && STCN_LOOKAHEAD=0 rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py "
-         "--streams 1 --steps 2 --warmup 1 --no-profile --cpu-frames 0 --no-f16x3-leg --no-r2 --no-config3 --no-memread-roofline`",
+         "--streams 1 --steps 2 --warmup 1 --no-profile --cpu-frames 0 --no-r2 --no-config3 --no-memread-roofline`",
          f"{frames // trace_bench['config']['frames_per_step']} videos x {trace_bench['config']['frames_per_step']} propagated frames (480x854, k=1, "
          "mem_freq=5), one video in flight, no side stream: the same solo launches bench.py's roofline leg times with HIP events.", "",
          f"Total kernel time {tot / 1e6:.1f} ms = {tot / 1e6 / frames:.2f} ms per propagated frame.", "",
@@ -80,7 +80,7 @@ if td:
     n2 = sum(float(r["TotalDurationNs"]) for r in cv)
     bd = last_json(os.path.join(SRC, "trace_default.log"))
     open(os.path.join(DST, f"{tag}_bench_default_kernel_stats.md"), "w").write(
-        f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --cpu-frames 0 --no-f16x3-leg --no-r2 --no-config3 --no-memread-roofline ({tag})\n\n"
+        f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --cpu-frames 0 --no-r2 --no-config3 --no-memread-roofline ({tag})\n\n"
         f"The default timed region: {bd['config']['streams_per_gpu']} videos in flight ({bd['value']:.1f} frames/s under the "
         f"profiler) plus the solo roofline leg, in one process.\nConv GEMMs (conv_gemm_kernel + wino_gemm_kernel): {c2} launches, {n2 / 1e6:.1f} ms, "
         f"average {n2 / c2 / 1e3:.2f} us per launch.  Kernels of concurrent videos overlap here, so this average is NOT the "
@@ -127,7 +127,7 @@ n = sum(kernels[k]["calls"] for k in cg)
 traffic = sum(kernels[k]["traffic_bytes_per_launch"] * kernels[k]["calls"] for k in cg) / n
 wk = [k for k in kernels if "wino_input_kernel" in k]
 out = dict(command="rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) --kernel-trace -- python3 bench.py --steps 1 --warmup 0 --streams 1 "
-                   "--no-profile --frames 30 --cpu-frames 0 --no-f16x3-leg --no-r2 --no-config3 --no-memread-roofline (STCN_LOOKAHEAD=0)",
+                   "--no-profile --frames 30 --cpu-frames 0 --no-r2 --no-config3 --no-memread-roofline (STCN_LOOKAHEAD=0)",
            units="counter values are KB per the rocprofv3 derived metric; gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reads 1/2 of the "
                  "bytes of wide (16 B/lane) coalesced reads -> doubled; WRITE_SIZE exact; Infinity-Cache hits are included (fabric-side counters)",
            conv_gemm_traffic_bytes_per_launch=traffic, conv_gemm_launches=n,
