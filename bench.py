@@ -260,7 +260,7 @@ DAVIS_VAL_LENGTHS = [69, 50, 80, 84, 90, 75, 40, 104, 90, 60, 66, 52, 50, 90, 78
 def config3_parity(prop, fuse, psd, fsd, T, H, W, k):
     """BASELINE config 3's shape on the CPU oracle AND the HIP engine (first T frames: k objects through the scribble path,
     mem_freq = 1): per-object mask IoU - over all pixels and over the pixels whose label is well-conditioned in the ORACLE's
-    own probabilities (top-1 minus top-2 >= 1e-3; with several objects the random-recipe decoder leaves large regions at
+    own probabilities (top-1 minus top-2 >= 1e-2; with several objects the random-recipe decoder leaves large regions at
     p ~ 1/(k+1) in every row, where the argmax hangs on the last ulp: tests/test_oracle_golden.py, seq480k5) - the worst
     frame, and the probability difference."""
     from eva_vos_amd import synth
@@ -278,7 +278,7 @@ def config3_parity(prop, fuse, psd, fsd, T, H, W, k):
     crop = lambda p_: p_[:, :, 0, lh:p_.shape[3] - uh if uh else None, lw:p_.shape[4] - uw if uw else None]      # noqa: E731
     po, pg = crop(orc.prob), crop(core.prob.cpu())
     top = torch.topk(po, 2, dim=0).values
-    dec = ((top[0] - top[1]) >= 1e-3).numpy()
+    dec = ((top[0] - top[1]) >= 1e-2).numpy()
     d = (po - pg).abs()
     out = dict(sample=f"first {T} frames of the config-3 workload ({H}x{W}, k={k}, mem_freq=1), interact(mask,0): CPU oracle {t_cpu:.1f} s",
                decisive_pixel_fraction=float(dec[1:].mean()), mask_pixels_differing=int((got != ref).sum()),

@@ -343,10 +343,11 @@ int run_conv(const Model &m, Work &w, hipStream_t s, const char *name, const flo
     p.affine_out = (y_bs == 0 || y_bs == (long)p.OH * p.OW * p.N) && (!res || (res_bs == (long)p.OH * p.OW * p.N && !res_bmod)) &&
                    ((long)p.M + 128) * p.N * 4 < (1L << 32);
     p.partial = w.splitk;
-    conv_plan(p, force_splitk, w.splitk_floats);
+    const bool fus = force_splitk <= 0 && fusion_conv_eligible(p);      // FusionNet shapes: the dedicated kernel
+    if (!fus) conv_plan(p, force_splitk, w.splitk_floats);
     const double fl = 2.0 * p.M * p.N * (double)(cw.kh * cw.kw * cw.cin);
     // stride-1 3x3 convs run as Winograd F(2x2,3x3) (2.25x fewer MFMA FLOP, exact-fp32 arithmetic) unless a split-K is forced
-    const size_t wino_need = force_splitk > 0 ? 0 : wino_workspace_floats(p);
+    const size_t wino_need = force_splitk > 0 || fus ? 0 : wino_workspace_floats(p);
     const bool wino = wino_need > 0 && wino_need <= w.wino_v_floats;
     const double fl_exec = wino ? 2.0 * (double)(wino_need / cw.cin_p) * cw.cin_p * p.N : fl;
     hipEvent_t *eg = nullptr, *er = nullptr, *ei = nullptr;
@@ -368,11 +369,12 @@ int run_conv(const Model &m, Work &w, hipStream_t s, const char *name, const flo
         if (wino) {
             ei = w.prof->attach(STCN_K_WINO_INPUT);
             if (wino_plan_splitk(p, w.splitk_floats) > 1) er = w.prof->attach(STCN_K_CONV_REDUCE);
-        } else if (p.splitk > 1 || p.rem_split > 1) {
+        } else if (!fus && (p.splitk > 1 || p.rem_split > 1)) {
             er = w.prof->attach(STCN_K_CONV_REDUCE);
         }
     }
-    if (wino) wino_launch(p, w.wino_v, w.splitk_floats, s, ei, eg, er);
+    if (fus) fusion_conv_launch(p, s, eg);
+    else if (wino) wino_launch(p, w.wino_v, w.splitk_floats, s, ei, eg, er);
     else conv_launch(p, s, eg, er);
     return launch_status(name);
 }
@@ -1053,8 +1055,8 @@ static int do_pass(stcn_engine *e, int idx, bool forward) {
                 const int cs = e->n_certain - 1;               // key of the current interaction
                 {
                     Scope sc(&e->prof, STCN_K_ATTENTION, e->stream, 2.0 * d.hw16 * d.hw16 * 64);
-                    attention_read_launch(e->bank_k + (size_t)cs * d.hw16 * 64, e->bank_msq + (size_t)cs * d.hw16, f.k16, e->pos,
-                                          e->neg, k + 1, d.h16, d.w16, w.pooled, w.amap, w.attn, AttnScratch{w.gmax, w.tau, w.cand_v}, e->stream);
+                    attention_read_launch(e->bank_k + (size_t)cs * d.hw16 * 64, e->bank_msq + (size_t)cs * d.hw16, f.k16, nullptr,
+                                          nullptr, k + 1, d.h16, d.w16, w.pooled, w.amap, w.attn, AttnScratch{w.gmax, w.tau, w.cand_v}, e->stream);
                 }
                 RC(launch_status("attention read"));
                 for (int o = 1; o <= k; ++o)
@@ -1094,6 +1096,7 @@ static int interact_run(stcn_engine *e, const float *mask_dev, int mask_channels
         interact_mask_launch(mask_dev, mask_channels, e->H, e->W, d.nh, d.nw, e->lw, e->lh, e->prob + (size_t)idx * d.npix,
                              (long)e->T * d.npix, kk, e->mask_pad, e->pos, e->neg, e->stream);
     }
+    attention_pool_launch(e->pos, e->neg, kk, d.h16, d.w16, e->work.pooled, e->stream);      // once per interaction, read by every fused frame
     RC(launch_status("interaction mask"));
     SlotPtrs kf;
     RC(ensure_key(e, idx, &kf));

@@ -78,6 +78,10 @@ void wino_launch(const ConvP &p, float *V, size_t slab_floats, hipStream_t s, hi
 int wino_plan_splitk(const ConvP &p, size_t slab_floats);
 void wino_transform_weights(const float *w, int N, int Cin, int Kp, float *U);
 
+// FusionNet convs (fusion_conv.hip): 3x3, stride 1, Cout = 32, Cin = 32 or 12, one dense image: weights in registers, patch in LDS
+bool fusion_conv_eligible(const ConvP &p);
+void fusion_conv_launch(const ConvP &p, hipStream_t s, hipEvent_t *ev_gemm = nullptr);
+
 // Cout == 1 convolution (decoder.pred, FusionNet.final_conv): one dot product per output pixel.
 // x [B,H,W,C] (C multiple of 4), w [KH*KW*C], y [B*H*W]; stride 1, "same" padding.
 void conv_n1_launch(const float *x, const float *w, float bias, float *y, int B, int H, int W, int C,
@@ -139,6 +143,8 @@ void memory_read_launch(const float *mk, const float *msq, const float *qk, int 
                         int32_t *topk_idx, float *topk_w, MemReadScratch scr, hipStream_t s);
 // fusion attention read: mk,qk [hw,64]; pos,neg [kk][16h*16w planes] -> attn [kk][2][nh*nw]
 struct AttnScratch { float *gmax, *cmax, *part; };   // [256][hw], [hw], [16][hw][19]
+// pos == nullptr: `pooled` already holds attention_pool_launch's output for this interaction
+void attention_pool_launch(const float *pos, const float *neg, int kk, int h, int w, float *pooled, hipStream_t s);
 void attention_read_launch(const float *mk, const float *msq, const float *qk, const float *pos,
                            const float *neg, int kk, int h, int w, float *pooled, float *amap,
                            float *attn, AttnScratch scr, hipStream_t s);

@@ -126,7 +126,7 @@ __device__ __forceinline__ void load_bq(const float *__restrict__ qk, int Q, int
 // conflict-free) and shared by the 4 waves - the first version of this read fetched the tile once per wave
 // straight from L2 and ran at ~0.4 of the fp32 MFMA rate on L2 bandwidth.
 //   COLLECT == false (pass 1): visits only every `ss`-th step (a strided SAMPLE of the bank) and keeps 16 running maxima
-//     per lane over disjoint row sets: gmax[(chunk*64 + 16*(lane>>4) + 4*rb + j)][q].  The 50th largest of >= 50 maxima of
+//     per lane over disjoint row sets: gmax[q][chunk*64 + 16*(lane>>4) + 4*rb + j].  The 50th largest of >= 50 maxima of
 //     disjoint subsets of the rows is a lower bound of the query's true 50th best score whatever the subsets are, so
 //     sampling costs tightness (expected rank ~ 52*ss instead of ~ 52), never exactness - and 1/ss of the MFMA work.
 //   COLLECT == true (pass 2): the full walk; scores above the query's threshold are appended to per-(query, chunk) lists
@@ -321,12 +321,12 @@ __global__ __launch_bounds__(256, SINGLE ? 3 : 2) void affinity_tile_kernel(
     }
     if (q0 >= Q) return;
     if (!COLLECT) {
+        // query-major [q][nc1 * 64]: threshold_kernel then reads one query's maxima as contiguous 256-byte runs (the first layout,
+        // [group][q], cost it 64 cache lines per load: 32 us for a 5 us job at 8100 queries)
         if (q0 + col < Q) {
+            float *dst = gmax + (long)(q0 + col) * ((long)gridDim.y * NGRP2) + chunk * NGRP2 + 16 * g;
 #pragma unroll
-            for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    gmax[((long)chunk * NGRP2 + 16 * g + 4 * rb + e) * Q + q0 + col] = 0.25f * gm[rb][e];
+            for (int rb = 0; rb < 4; ++rb) *reinterpret_cast<f32x4 *>(dst + 4 * rb) = gm[rb] * 0.25f;
         }
         return;
     }
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256) void threshold_kernel(const float *__restrict_
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int gi = lane + 64 * e;
-        const float v = gi < G ? gmax[(long)gi * Q + q] : -__builtin_inff();
+        const float v = gi < G ? gmax[(long)q * G + gi] : -__builtin_inff();
         k[e] = v > -__builtin_inff() ? f2key(v) : 0u;
     }
     unsigned prefix = 0;
@@ -629,21 +629,12 @@ __global__ void area_pool16_kernel(const float *__restrict__ pos, const float *_
 }
 
 #define STCN_ATT_MAXCH 18   // (k+1)*2 with k <= 8
-// cmax[q] = max over the G group maxima of pass 1 = exact column maximum of S
-__global__ void colmax_kernel(const float *__restrict__ gmax, int G, int Q, float *__restrict__ cmax) {
-    const int q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= Q) return;
-    float m = -__builtin_inff();
-    for (int g = 0; g < G; ++g) m = fmaxf(m, gmax[(long)g * Q + q]);
-    cmax[q] = m;
-}
-
-// pass 2 of the attention read: per (query block, row chunk) partial sums of e = exp(S - cmax[q]):
+// pass 2 of the attention read: per (query block, row chunk) partial sums of e = exp(S - cmax[q]), cmax = exact column maximum:
 //   part[chunk][q][0] = sum_m e,  part[chunk][q][1 + c] = sum_m e * pooled[c][m]
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void attention_pass_kernel(
     const float *__restrict__ mk, const float *__restrict__ msq, const float *__restrict__ qk, int N, int Q,
-    int steps_per_chunk, const float *__restrict__ cmax, const float *__restrict__ pooled, int nch,
+    int steps_per_chunk, const float *__restrict__ gmax, int G, const float *__restrict__ pooled, int nch,
     float *__restrict__ part) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q0 = (blockIdx.x * WAVES + wave) * 16;
@@ -656,7 +647,13 @@ __global__ __launch_bounds__(64 * WAVES) void attention_pass_kernel(
     const int qcol = min(q0 + col, Q - 1);
     f32x4 bq[4];
     load_bq(qk, Q, q0, lane, bq);
-    const float cm = cmax[qcol];
+    // exact column maximum of S = max over the G group maxima of pass 1 ([G][Q]): the four lane groups of a column take every
+    // fourth group (independent loads in flight) and combine with two shuffles.  (A separate one-thread-per-query kernel walked
+    // the 256 groups serially: 52 us for 1620 queries, 3 % of a round-2 frame.)
+    float cm = -__builtin_inff();
+    for (int gi = g; gi < G; gi += 4) cm = fmaxf(cm, gmax[(long)gi * Q + qcol]);
+    cm = fmaxf(cm, __shfl_xor(cm, 16));
+    cm = fmaxf(cm, __shfl_xor(cm, 32));
     float l = 0.f, a[STCN_ATT_MAXCH];
 #pragma unroll
     for (int c = 0; c < STCN_ATT_MAXCH; ++c) a[c] = 0.f;
@@ -734,12 +731,17 @@ __global__ void bilinear_up16_kernel(const float *__restrict__ amap, int nch, in
              fy * ((1.f - fx) * a[y1 * w + x0] + fx * a[y1 * w + x1]);
 }
 
+// pooled [kk][2][h*w] = 16x16 block means of the +/- mask differences of the current interaction: the same for every frame
+// of the round, so the engine computes it once per interaction (pos == nullptr below)
+void attention_pool_launch(const float *pos, const float *neg, int kk, int h, int w, float *pooled, hipStream_t s) {
+    hipLaunchKernelGGL(area_pool16_kernel, dim3((unsigned)(((long)kk * 2 * h * w + 255) / 256)), dim3(256), 0, s, pos, neg, kk, h, w, pooled);
+}
+
 void attention_read_launch(const float *mk, const float *msq, const float *qk, const float *pos, const float *neg,
                            int kk, int h, int w, float *pooled, float *amap, float *attn, AttnScratch scr,
                            hipStream_t s) {
     const int hw = h * w, nch = kk * 2;
-    hipLaunchKernelGGL(area_pool16_kernel, dim3((unsigned)(((long)nch * hw + 255) / 256)), dim3(256), 0, s, pos, neg,
-                       kk, h, w, pooled);
+    if (pos) attention_pool_launch(pos, neg, kk, h, w, pooled, s);
     constexpr int WAVES = 4;
     const int steps = (hw + HROWS - 1) / HROWS;
     const int qblocks = (hw + 16 * WAVES - 1) / (16 * WAVES);
@@ -750,8 +752,7 @@ void attention_read_launch(const float *mk, const float *msq, const float *qk, c
     const int NCeff = (steps + spc - 1) / spc;
     const dim3 grid(qblocks, NCeff);
     hipLaunchKernelGGL((colmax_pass_kernel<WAVES>), grid, dim3(64 * WAVES), 0, s, mk, msq, qk, hw, hw, spc, scr.gmax);
-    hipLaunchKernelGGL(colmax_kernel, dim3((hw + 255) / 256), dim3(256), 0, s, scr.gmax, NCeff * NGRP, hw, scr.cmax);
-    hipLaunchKernelGGL((attention_pass_kernel<WAVES>), grid, dim3(64 * WAVES), 0, s, mk, msq, qk, hw, hw, spc, scr.cmax,
+    hipLaunchKernelGGL((attention_pass_kernel<WAVES>), grid, dim3(64 * WAVES), 0, s, mk, msq, qk, hw, hw, spc, scr.gmax, NCeff * NGRP,
                        pooled, nch, scr.part);
     hipLaunchKernelGGL(attention_finalize_kernel, dim3((hw + 255) / 256), dim3(256), 0, s, scr.part, NCeff, hw, nch,
                        amap);

@@ -224,7 +224,9 @@ def seq_case(tag, H, W, k, T, mem_freq, script, net, fus, psd, fsd, out, prob_st
             # pixels whose label is well-conditioned in the REFERENCE's own probabilities (top-1 minus top-2 >= eps), packed
             # bits over the unpadded [T,H,W]: with several objects a random-weight decoder leaves whole regions at p ~ 1/(k+1)
             # for every row, where the argmax is decided by the last ulp and no two executions agree (not even two thread
-            # counts of the reference: selfnoise).  Mask parity is stated on these pixels; probabilities everywhere.
+            # counts of the reference: selfnoise).  eps = 1e-2 = what ONE swapped top-50 member at a near-tie moves the
+            # probabilities of its neighbourhood by (tests/test_gpu_kernels.py::test_near_tie_...): below that margin a label
+            # depends on fp32 rounding of the affinity.  Mask parity is stated on these pixels; probabilities everywhere.
             lw, uw, lh, uh = ref.pad
             pr = ref.prob[:, :, 0, lh:ref.prob.shape[3] - uh if uh else None, lw:ref.prob.shape[4] - uw if uw else None]
             top = torch.topk(pr, 2, dim=0).values
@@ -256,8 +258,8 @@ SEQ_CASES = {
 FULL_CASES = {
     "seq480": dict(H=480, W=854, k=1, T=6, mem_freq=2, script=[(0, 0), (4, 4)], prob_stride=4),
     # BASELINE config 3 shape from the reference: 5 objects through the scribble / (k+1)-channel path, every frame enters the
-    # bank (mem_freq = 1), 12 frames 480x854; uint8 masks + every 8th prob sample as fp16.  Self-noise on 2 / 4 / 8 threads.
-    "seq480k5": dict(H=480, W=854, k=5, T=12, mem_freq=1, script=[(0, 0)], prob_stride=8, threads=(2, 4, 8), decisive_eps=1e-3),
+    # bank (mem_freq = 1), 12 frames 480x854; uint8 masks + every 8th prob sample as fp16.  Self-noise on 1 / 4 / 8 threads.
+    "seq480k5": dict(H=480, W=854, k=5, T=12, mem_freq=1, script=[(0, 0)], prob_stride=8, threads=(1, 4, 8), decisive_eps=1e-2),
 }
 STAGE_CASES = {
     "stA": dict(H=128, W=160, k=1),

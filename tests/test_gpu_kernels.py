@@ -20,6 +20,9 @@ CONVS = [
     (2, 48, 64, 8, 64, 7, 2, 2, 0),         # value stem (Cin padded 5->8), batch 2
     (1, 40, 56, 12, 32, 3, 1, 2, 0),        # fusion conv1 (9->12 channels), narrow tile
     (1, 40, 56, 32, 32, 3, 1, 0, 0),        # fusion 32->32 + residual
+    (1, 21, 37, 32, 32, 3, 1, 2, 0),        # FusionNet kernel: rows not a multiple of the 8-row patch, ragged second column tile
+    (1, 9, 70, 12, 32, 3, 1, 2, 0),         # ... its 12-channel instance, three column tiles
+    (1, 480, 864, 32, 32, 3, 1, 2, 0),      # ... at the size it runs at (1620 patches: more than one round of workgroups)
     (1, 9, 7, 64, 64, 1, 1, 0, 0),          # tiny
     (1, 15, 27, 1280, 512, 3, 1, 1, 0),     # fuser-like big K, relu in, auto split
     (1, 30, 54, 256, 1, 3, 1, 1, 0),        # decoder.pred (Cout 1), relu in

@@ -25,7 +25,7 @@ CLEAN_FP32 = 2e-4     # max |prob| difference between two fp32 implementations w
 def clean_frame_check(core_prob, orc, rounds_done, tag):
     """HIP vs oracle, fp32 against fp32: on the frames propagated before the first near-tie of the run (tie_summary) the
     probabilities agree EVERYWHERE to CLEAN_FP32 - a max, not a quantile."""
-    info = tie_summary(orc)[rounds_done]
+    info = tie_summary(orc).get(rounds_done, dict(clean=set(), near=0, queries=0))      # a 1-frame clip has no memory read at all
     clean = sorted(info["clean"])
     d = (core_prob - orc.prob).abs()
     worst = float(d[:, clean].max()) if clean else 0.0
@@ -503,7 +503,7 @@ def test_a_failing_interaction_leaves_a_defined_state(nets):
     want1 = ref.interact(msk[:, 2], 2).copy()
     want2 = ref.interact(msk[:, 6], 6).copy()
     prob2 = ref.prob.clone()
-    for n in (1, 3, 40, 110):                  # at the first launch, in the certain-memory value encode, in either sweep
+    for n in (1, 3, 25, 50):                   # at the first launch, in the certain-memory value encode, in either sweep (~65 checks)
         core = make_core(nets)(img, 1, 3)
         assert np.array_equal(core.interact(msk[:, 2], 2), want1)
         _lib.check(_lib.lib().stcn_test_fail_at(n))

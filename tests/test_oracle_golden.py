@@ -136,10 +136,11 @@ def check_sequence_against_golden(outs, tag, g, prob_atol, min_iou=1 - 1e-3, tie
         if k == 1:
             ref_masks = np.unpackbits(ref_masks)[: T * H * W].reshape(T, H, W)
         # Fixtures with a `decisive` bitmask (seq480k5): the pixels whose label is well-conditioned in the REFERENCE's own
-        # probabilities (top-1 minus top-2 >= 1e-3).  With 5 objects the random-recipe decoder leaves half of the frame at
-        # p ~ 1/(k+1) in every row; there the argmax hangs on the last ulp (the reference's own thread counts disagree on 4297
-        # pixels, two correct fp32 implementations with different rounding - BN folded or not - on ~2e4), so mask parity is
-        # stated on the decisive pixels, at the north_star bound, and the probabilities are compared everywhere below.
+        # probabilities (top-1 minus top-2 >= 1e-2 = what one swapped top-50 member at a near-tie moves its neighbourhood by).
+        # With 5 objects the random-recipe decoder leaves most of the frame at p ~ 1/(k+1) in every row; there the argmax hangs
+        # on fp32 rounding (the reference's own thread counts disagree on 4297 pixels, two correct fp32 implementations with
+        # different rounding - BN folded or not - on ~2e4, all of them inside that margin), so mask parity is stated on the
+        # decisive pixels, at the north_star bound, and the probabilities are compared everywhere below.
         dec = None
         if f"{tag}.r{r}.decisive" in g:
             dec = np.unpackbits(g[f"{tag}.r{r}.decisive"])[: T * H * W].reshape(T, H, W).astype(bool)
