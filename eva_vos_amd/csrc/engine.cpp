@@ -103,6 +103,18 @@ int make_wino(Model &m, ConvW &cw, const std::vector<float> &w) {
     return upload(m, u, &cw.wino_u);
 }
 
+int make_wino4(Model &m, ConvW &cw, const std::vector<float> &w) {
+    static const bool on = [] { const char *e = getenv("STCN_WINO4"); return !e || atoi(e) != 0; }();
+    if (!on || cw.kh != 3 || cw.kw != 3 || cw.cin_p % 32 || cw.cin_p < 128 || cw.cout % 32) return STCN_OK;
+    std::vector<float> u((size_t)36 * cw.cin_p * cw.cout);
+    wino4_transform_weights(w.data(), cw.cout, cw.cin_p, cw.Kp, u.data());
+    return upload(m, u, &cw.wino4_u);
+}
+
+// F(4x4,3x3) is reserved for the decoder side (its outputs become probabilities and memory values, never the keys that decide
+// top-50 membership): the decoder proper and its frame-only skip convs
+static bool decoder_layer(const std::string &name) { return name.compare(0, 8, "decoder.") == 0; }
+
 static int add_convs(Model &m, const std::map<std::string, HostT> &sd) {
     for (auto &kv : sd) {
         const std::string &name = kv.first;
@@ -146,6 +158,7 @@ static int add_convs(Model &m, const std::map<std::string, HostT> &sd) {
         rc = upload(m, bias, &cw.bias);
         if (rc) return rc;
         if ((rc = make_wino(m, cw, w))) return rc;
+        if (decoder_layer(pre) && (rc = make_wino4(m, cw, w))) return rc;
         cw.bias0 = bias[0];
         m.conv[pre] = cw;
         // Convs over a channel concat [per-object part | frame-only part]: conv is linear in the input
@@ -171,6 +184,7 @@ static int add_convs(Model &m, const std::map<std::string, HostT> &sd) {
                 std::vector<float> bb = part ? bias : std::vector<float>(cout, 0.f);
                 if ((rc = upload(m, ww, &pw.w)) || (rc = upload(m, bb, &pw.bias))) return rc;
                 if ((rc = make_wino(m, pw, ww))) return rc;
+                if (decoder_layer(pre) && (rc = make_wino4(m, pw, ww))) return rc;
                 pw.bias0 = bb[0];
                 m.conv[pre + (part ? "#b" : "#a")] = pw;
             }
@@ -334,7 +348,7 @@ int run_conv(const Model &m, Work &w, hipStream_t s, const char *name, const flo
     p.x1_bytes = (unsigned)x1b;
     p.w_bytes = (unsigned)((long)cw.cout * cw.Kp * 4);
     if (x1 && ((cw.cin_p % 32) || (c0 % 32) || cw.kh * cw.kw > 32)) { set_error("conv '%s': two-source input needs 32-aligned channel splits", name); return STCN_E_INVALID; }
-    p.w = cw.w; p.wino_u = cw.wino_u;
+    p.w = cw.w; p.wino_u = cw.wino_u; p.wino4_u = cw.wino4_u;
     p.bias = cw.bias; p.res = res; p.res_bs = res_bs; p.res_bmod = res_bmod; p.y = y; p.y_bs = y_bs;
     p.relu_in = relu_in; p.relu_out = relu_out;
     p.fd_ohw = fastdiv_make((unsigned)(p.OH * p.OW));
@@ -347,9 +361,12 @@ int run_conv(const Model &m, Work &w, hipStream_t s, const char *name, const flo
     if (!fus) conv_plan(p, force_splitk, w.splitk_floats);
     const double fl = 2.0 * p.M * p.N * (double)(cw.kh * cw.kw * cw.cin);
     // stride-1 3x3 convs run as Winograd F(2x2,3x3) (2.25x fewer MFMA FLOP, exact-fp32 arithmetic) unless a split-K is forced
-    const size_t wino_need = force_splitk > 0 || fus ? 0 : wino_workspace_floats(p);
+    // decoder-side layers with enough tiles: F(4x4,3x3) (4x fewer MFMA FLOP); else F(2x2,3x3) (2.25x fewer)
+    const size_t wino4_need = force_splitk > 0 || fus ? 0 : wino4_workspace_floats(p, m.wino4_min_wg);
+    const bool wino4 = wino4_need > 0 && wino4_need <= w.wino_v_floats;
+    const size_t wino_need = force_splitk > 0 || fus || wino4 ? 0 : wino_workspace_floats(p);
     const bool wino = wino_need > 0 && wino_need <= w.wino_v_floats;
-    const double fl_exec = wino ? 2.0 * (double)(wino_need / cw.cin_p) * cw.cin_p * p.N : fl;
+    const double fl_exec = wino4 ? 2.0 * (double)wino4_need * p.N : (wino ? 2.0 * (double)(wino_need / cw.cin_p) * cw.cin_p * p.N : fl);
     hipEvent_t *eg = nullptr, *er = nullptr, *ei = nullptr;
     if (w.prof) {
         // algorithmic bytes: the input tensors (dense data, not the descriptor extents; a broadcast source once), weights,
@@ -366,7 +383,9 @@ int run_conv(const Model &m, Work &w, hipStream_t s, const char *name, const flo
         w.prof->exec_flops[cls] += fl_exec;
         if (hbm_acc) { w.prof->hbm_conv_bytes += bytes; w.prof->hbm_conv_flops += fl; }
         eg = w.prof->attach(cls, hbm_acc);
-        if (wino) {
+        if (wino4) {
+            ei = w.prof->attach(STCN_K_WINO_INPUT);
+        } else if (wino) {
             ei = w.prof->attach(STCN_K_WINO_INPUT);
             if (wino_plan_splitk(p, w.splitk_floats) > 1) er = w.prof->attach(STCN_K_CONV_REDUCE);
         } else if (!fus && (p.splitk > 1 || p.rem_split > 1)) {
@@ -374,6 +393,7 @@ int run_conv(const Model &m, Work &w, hipStream_t s, const char *name, const flo
         }
     }
     if (fus) fusion_conv_launch(p, s, eg);
+    else if (wino4) wino4_launch(p, w.wino_v, s, ei, eg);
     else if (wino) wino_launch(p, w.wino_v, w.splitk_floats, s, ei, eg, er);
     else conv_launch(p, s, eg, er);
     return launch_status(name);

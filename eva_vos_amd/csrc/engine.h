@@ -19,6 +19,8 @@ struct Model;
 struct ConvW;
 // builds the Winograd weights of a stride-1-capable 3x3 conv from its repacked fp32 host weights (no-op when not eligible)
 int make_wino(Model &m, ConvW &cw, const std::vector<float> &w_host);
+// F(4x4,3x3) weights of a decoder-side 3x3 conv (no-op when not eligible)
+int make_wino4(Model &m, ConvW &cw, const std::vector<float> &w_host);
 #define HIPCHK(x)                                                                          \
     do {                                                                                   \
         hipError_t e_ = (x);                                                               \
@@ -31,6 +33,7 @@ int make_wino(Model &m, ConvW &cw, const std::vector<float> &w_host);
 struct ConvW {
     float *w = nullptr, *bias = nullptr;   // device: [Cout][Kp], [Cout]
     float *wino_u = nullptr;               // device: Winograd F(2x2,3x3) weights [16][Cin/8][Cout][8] (eligible 3x3 convs)
+    float *wino4_u = nullptr;              // device: Winograd F(4x4,3x3) weights [36][Cin/8][Cout][8] (decoder layers)
     float bias0 = 0.f;                     // host copy of bias[0] (Cout == 1 convs)
     int cout = 0, cin = 0, cin_p = 0, kh = 0, kw = 0, K = 0, Kp = 0;
 };
@@ -40,6 +43,7 @@ struct Model {
     std::map<std::string, ConvW> conv;
     CbamW cbam{};
     bool has_fuse = false;
+    int wino4_min_wg = 384;                // fewest workgroups for which a flagged layer takes the F(4x4) kernel (tests: 0)
     std::vector<void *> allocs;
     const ConvW &c(const std::string &name) const;
 };

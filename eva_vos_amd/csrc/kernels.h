@@ -57,6 +57,7 @@ struct ConvP {
     // ([(tile - rem_full) * rem_split + piece][BM][BN]) and are summed by conv_reduce_tiles_kernel
     int rem_full, rem_split, rem_per;
     const float *wino_u;    // Winograd-transformed weights [16][Cin/8][N][8] (stride-1 3x3 convs with Cin >= 64, N % 64 == 0) or nullptr
+    const float *wino4_u;   // Winograd F(4x4,3x3) weights [36][Cin/8][N][8] (decoder layers only: winograd4.hip) or nullptr
     FastDiv fd_ohw, fd_ow;  // divisions by OH*OW and OW
     int pointwise;          // 1x1, stride 1, no padding, one dense source: im2col row m IS activation row m (no row decode)
     int affine_out;         // y (and res, if any) are dense [M][N]: element (m, n) at (m * N + n) * 4 bytes, < 4 GiB
@@ -77,6 +78,10 @@ void wino_launch(const ConvP &p, float *V, size_t slab_floats, hipStream_t s, hi
                  hipEvent_t *ev_red = nullptr);
 int wino_plan_splitk(const ConvP &p, size_t slab_floats);
 void wino_transform_weights(const float *w, int N, int Cin, int Kp, float *U);
+// Winograd F(4x4,3x3) path (winograd4.hip, decoder layers): V workspace floats, or 0 when not eligible / fewer than min_wg workgroups
+size_t wino4_workspace_floats(const ConvP &p, int min_wg);
+void wino4_launch(const ConvP &p, float *V, hipStream_t s, hipEvent_t *ev_in = nullptr, hipEvent_t *ev_gemm = nullptr);
+void wino4_transform_weights(const float *w, int N, int Cin, int Kp, float *U);
 
 // FusionNet convs (fusion_conv.hip): 3x3, stride 1, Cout = 32, Cin = 32 or 12, one dense image: weights in registers, patch in LDS
 bool fusion_conv_eligible(const ConvP &p);

@@ -42,6 +42,14 @@ CONVS = [
     (1, 14, 18, 1024, 64, 3, 1, 0, 0),
     (2, 10, 12, 1024, 512, 3, 1, 3, 0),
     (2, 30, 54, 1024, 128, 3, 1, 2, 0),     # enough tiles for an unsplit launch of the 8-wave instance
+    # F(4x4,3x3) (flags bit 2 = "decoder layer"): ragged tiles (sizes not multiples of 4), batch with residual and ReLUs, a
+    # partially filled workgroup tile, Cout = 32 (one n-tile) and 192, and the shapes it runs at (1/4 and 1/8 scale)
+    (2, 17, 23, 128, 128, 3, 1, 7, 0),
+    (1, 31, 45, 256, 64, 3, 1, 4, 0),
+    (3, 16, 20, 512, 192, 3, 1, 6, 0),
+    (1, 6, 5, 128, 32, 3, 1, 5, 0),
+    (1, 120, 216, 256, 256, 3, 1, 5, 0),
+    (2, 60, 108, 512, 256, 3, 1, 6, 0),
     # pointwise instance (1x1, stride 1): ragged M, residual + ReLU, split-K, and the stride-2 1x1 that must NOT take it
     (2, 19, 21, 256, 192, 1, 1, 2, 0),
     (1, 30, 54, 512, 128, 1, 1, 0, 3),
@@ -70,6 +78,7 @@ def test_conv_matches_fp64_reference(B, H, W, Cin, Cout, K, s, flags, splitk, mo
         ref = F.relu(ref)
     # Winograd-eligible shapes run under BOTH GEMM instances (16 waves x 1 position, 8 waves x 2 positions), whatever the
     # default choice for their channel count is
+    monkeypatch.setenv("STCN_FUSION_CONV12", "1")          # the 12-channel instance of the FusionNet kernel is off by default
     for ppw in (("1", "2") if _is_wino(Cin, Cout, K, s, splitk) else (None,)):
         if ppw:
             monkeypatch.setenv("STCN_WINO_PPW", ppw)
