@@ -44,7 +44,10 @@ static constexpr int WN = 64;        // output channels per workgroup
 __global__ __launch_bounds__(256) void wino_input_kernel(const float *__restrict__ x, long x_bs, int H, int W, int C, int relu_in,
                                                          int TH, int TW, int Mt, int Mt_pad, int cb_per_chunk,
                                                          float *__restrict__ V) {
-    const long i = blockIdx.x * 256L + threadIdx.x;
+    // XCD-contiguous block order (neighbouring tile rows share pixel rows: keep them in one L2)
+    const int nbx = gridDim.x, q8 = nbx >> 3, r8 = nbx & 7, xcd = blockIdx.x & 7;
+    const int bx = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+    const long i = bx * 256L + threadIdx.x;
     const int c16 = (int)(i & 7);
     const long tile = i >> 3;
     if (tile >= Mt_pad) return;
@@ -65,6 +68,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float *__restrict
     const float *xb = x + (long)b * x_bs + ((long)y0 * W + x0) * C + 4 * c16;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     const long ps = ((long)KB * Mt_pad) << 3;                // floats between positions
+    const float lo = relu_in ? 0.f : -__builtin_inff();      // ReLU or identity without a branch per load (a branch there makes hipcc drain vmcnt per load)
     for (int cb = cb0; cb < cb1; ++cb) {
         f32x4 d[4][4];
 #pragma unroll
@@ -73,7 +77,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float *__restrict
             for (int xx = 0; xx < 4; ++xx) {
                 f32x4 v = zero;
                 if (ok[yy][xx]) v = *reinterpret_cast<const f32x4 *>(xb + ((long)yy * W + xx) * C + 32 * cb);
-                if (relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                v.x = fmaxf(v.x, lo); v.y = fmaxf(v.y, lo); v.z = fmaxf(v.z, lo); v.w = fmaxf(v.w, lo);      // ReLU or identity, branchless
                 d[yy][xx] = v;
             }
         f32x4 t[4][4];                                       // B^T d

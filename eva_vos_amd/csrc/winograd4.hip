@@ -56,7 +56,11 @@ __device__ __forceinline__ void bt6(const f32x4 &d0, const f32x4 &d1, const f32x
 __global__ __launch_bounds__(256) void wino4_input_kernel(const float *__restrict__ x, unsigned x_bytes, long x_bs, int H, int W, int C,
                                                           int relu_in, int TH, int TW, int Mt, int Mt_pad, int cb_per_chunk,
                                                           float *__restrict__ V) {
-    const long i = blockIdx.x * 256L + threadIdx.x;
+    // XCD-contiguous block order: neighbouring tile rows share two pixel rows; dealt round-robin over the XCDs (the dispatcher's
+    // order) those rows were fetched into two L2s - FETCH_SIZE 2.1x the input
+    const int nbx = gridDim.x, q8 = nbx >> 3, r8 = nbx & 7, xcd = blockIdx.x & 7;
+    const int bx = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+    const long i = bx * 256L + threadIdx.x;
     const int c16 = (int)(i & 7);
     const long tile = i >> 3;
     if (tile >= Mt_pad) return;
@@ -79,6 +83,9 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float *__restric
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x), 0, x_bytes, 0x00020000);
     const int xoff = (int)((b * x_bs + ((long)y0 * W + x0) * C + 4 * c16) * 4);      // may be negative at the border: only used when valid
     const long ps = ((long)KB * Mt_pad) << 3;                // floats between positions
+    // a branch on relu_in around each load makes hipcc wait vmcnt(0) per load: 36 serialized round trips (measured: 125 us
+    // for a 79 us job).  max(v, lo) with lo = 0 or -inf is the same arithmetic without the branch.
+    const float lo = relu_in ? 0.f : -__builtin_inff();
     for (int cb = cb0; cb < cb1; ++cb) {
         f32x4 t[6][6];                                       // t = B^T d (columns transformed), row by row of the input
 #pragma unroll
@@ -88,7 +95,7 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float *__restric
             for (int yy = 0; yy < 6; ++yy) {
                 const unsigned vo = ((ok >> (yy * 6 + xx)) & 1ull) ? (unsigned)(xoff + ((yy * W + xx) * C + 32 * cb) * 4) : 0x80000000u;
                 f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, vo, 0, 0));
-                if (relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                v.x = fmaxf(v.x, lo); v.y = fmaxf(v.y, lo); v.z = fmaxf(v.z, lo); v.w = fmaxf(v.w, lo);      // ReLU or identity, branchless
                 d[yy] = v;
             }
             bt6(d[0], d[1], d[2], d[3], d[4], d[5], t[0][xx], t[1][xx], t[2][xx], t[3][xx], t[4][xx], t[5][xx]);
@@ -119,129 +126,197 @@ struct Wino4G {
     FastDiv fd_tpi, fd_tw, fd_tiles_n;
 };
 
+// MB = 32-tile blocks per workgroup.  MB = 1: three fragment sets, loads two k-blocks ahead.  MB = 2 (64 tiles x 32 channels: 25 %
+// fewer L2 bytes per MFMA, half the U traffic): 96 accumulator registers leave room for two HALF fragment sets - the loop walks
+// half-steps (k-block, 32-tile block) and loads one half-step ahead (12 MFMAs x 3 waves sharing the SIMD: ~2300 cycles).
+template <int MB>
 __global__ __launch_bounds__(64 * W4W) void wino4_gemm_kernel(const Wino4G p, const int tiles_n, const int dbg) {
-    constexpr int PPW = 3;
+    constexpr int PPW = 3, WT = W4T * MB;
     extern __shared__ __attribute__((aligned(16))) float smem[];          // epilogue: [36][32 tiles][32 channels]
     const int nblk = gridDim.x;
     const int q8 = nblk >> 3, r8 = nblk & 7, xcd = blockIdx.x & 7;
     const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
     const int tm = fastdiv(swz, p.fd_tiles_n), tn = swz - tm * tiles_n;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, h = lane >> 5;
+    const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);                  // wave-uniform: the position offsets below stay in SGPRs
     const int pos0 = PPW * wave;
 
     const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.V), 0, p.v_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.U), 0, p.u_bytes, 0x00020000);
-    unsigned va[PPW], vb[PPW];
+    // one lane offset; position / block / k-block offsets are wave-uniform and ride in the scalar offset of the buffer loads
+    const unsigned vl = (unsigned)(l31 * 32 + h * 16);
+    unsigned sa0[PPW], sb0[PPW];
 #pragma unroll
     for (int pi = 0; pi < PPW; ++pi) {
-        va[pi] = (unsigned)((((long)(pos0 + pi) * p.KB) * p.Mt_pad + tm * W4T + l31) * 32 + h * 16);
-        vb[pi] = (unsigned)((((long)(pos0 + pi) * p.KB) * p.N + tn * W4N + l31) * 32 + h * 16);
+        sa0[pi] = (unsigned)((((long)(pos0 + pi) * p.KB) * p.Mt_pad + tm * WT) * 32);
+        sb0[pi] = (unsigned)((((long)(pos0 + pi) * p.KB) * p.N + tn * W4N) * 32);
     }
-    const unsigned sa = (unsigned)p.Mt_pad * 32u, sb = (unsigned)p.N * 32u;   // bytes per k-block
+    unsigned sa = (unsigned)p.Mt_pad * 32u, sb = (unsigned)p.N * 32u;   // bytes per k-block
+    if (dbg & 2) { sa = 0; sb = 0; for (int pi = 0; pi < PPW; ++pi) { sa0[pi] = 0; sb0[pi] = 0; } }
 
-    f32x16 acc[PPW];
+    f32x16 acc[PPW][MB];
 #pragma unroll
     for (int pi = 0; pi < PPW; ++pi)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[pi][e] = 0.f;
-
-    auto load = [&](int k, f32x4 (&fa)[PPW], f32x4 (&fb)[PPW]) {
-        const unsigned oa = (unsigned)k * sa, ob = (unsigned)k * sb;
+        for (int bi = 0; bi < MB; ++bi)
 #pragma unroll
-        for (int pi = 0; pi < PPW; ++pi) {
-            fa[pi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rv, va[pi], oa, 0));
-            fb[pi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ru, vb[pi], ob, 0));
-        }
+            for (int e = 0; e < 16; ++e) acc[pi][bi][e] = 0.f;
+
+    const int nk = p.KB;
+    auto load1 = [&](int k, int pi, f32x4 (&fa)[MB], f32x4 &fb) {
+        const unsigned oa = sa0[pi] + (unsigned)k * sa, ob = sb0[pi] + (unsigned)k * sb;
+#pragma unroll
+        for (int bi = 0; bi < MB; ++bi) fa[bi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rv, vl, oa + bi * 1024u, 0));
+        fb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ru, vl, ob, 0));
     };
-    auto compute = [&](const f32x4 (&fa)[PPW], const f32x4 (&fb)[PPW]) {
+    auto compute1 = [&](int pi, const f32x4 (&fa)[MB], const f32x4 &fb) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int pi = 0; pi < PPW; ++pi)
-                acc[pi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[pi][j], fb[pi][j], acc[pi], 0, 0, 0);
+            for (int bi = 0; bi < MB; ++bi) acc[pi][bi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[bi][j], fb[j], acc[pi][bi], 0, 0, 0);
     };
-    const int nk = p.KB;
-    {
+    if (MB == 1) {
         // three fragment sets: the loads of k-block k+2 are issued before the MFMAs of k-block k (as wino_gemm_kernel)
-        f32x4 fa0[PPW], fb0[PPW], fa1[PPW], fb1[PPW], fa2[PPW], fb2[PPW];
-        load(0, fa0, fb0);
-        load(min(1, nk - 1), fa1, fb1);
+        f32x4 fa[3][PPW][MB], fb[3][PPW];
+        auto load = [&](int k, int set) {
+#pragma unroll
+            for (int pi = 0; pi < PPW; ++pi) load1(k, pi, fa[set][pi], fb[set][pi]);
+        };
+        auto compute = [&](int set) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int pi = 0; pi < PPW; ++pi)
+#pragma unroll
+                    for (int bi = 0; bi < MB; ++bi)
+                        acc[pi][bi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][pi][bi][j], fb[set][pi][j], acc[pi][bi], 0, 0, 0);
+        };
+        load(0, 0);
+        load(min(1, nk - 1), 1);
         int k = 0;
         for (; k + 2 < nk; k += 3) {
-            load(k + 2, fa2, fb2);
+            load(k + 2, 2);
             __builtin_amdgcn_sched_barrier(0);
-            compute(fa0, fb0);
+            compute(0);
             __builtin_amdgcn_sched_barrier(0);
-            load(min(k + 3, nk - 1), fa0, fb0);
+            load(min(k + 3, nk - 1), 0);
             __builtin_amdgcn_sched_barrier(0);
-            compute(fa1, fb1);
+            compute(1);
             __builtin_amdgcn_sched_barrier(0);
-            load(min(k + 4, nk - 1), fa1, fb1);
+            load(min(k + 4, nk - 1), 1);
             __builtin_amdgcn_sched_barrier(0);
-            compute(fa2, fb2);
+            compute(2);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (k < nk) compute(fa0, fb0);
-        if (k + 1 < nk) compute(fa1, fb1);
+        if (k < nk) compute(0);
+        if (k + 1 < nk) compute(1);
+    } else {
+        // half-steps (k, bi): A fragments of ONE 32-tile block per position (set = bi), B fragments per k-block (set = k & 1);
+        // the loads of half-step s + 1 are issued before the 12 MFMAs of half-step s.  Two k-blocks per loop body (nk is a
+        // multiple of 4).
+        f32x4 fa[2][PPW], fb[2][PPW];
+        auto loadA = [&](int k, int bi, f32x4 (&d)[PPW]) {
+#pragma unroll
+            for (int pi = 0; pi < PPW; ++pi)
+                d[pi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rv, vl, sa0[pi] + (unsigned)k * sa + bi * 1024u, 0));
+        };
+        auto loadB = [&](int k, f32x4 (&d)[PPW]) {
+#pragma unroll
+            for (int pi = 0; pi < PPW; ++pi)
+                d[pi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ru, vl, sb0[pi] + (unsigned)k * sb, 0));
+        };
+        auto comp = [&](int bi, const f32x4 (&a)[PPW], const f32x4 (&bb)[PPW]) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int pi = 0; pi < PPW; ++pi) acc[pi][bi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[pi][j], bb[pi][j], acc[pi][bi], 0, 0, 0);
+        };
+        loadB(0, fb[0]);
+        loadA(0, 0, fa[0]);
+        for (int k = 0; k < nk; k += 2) {
+            const int k2 = min(k + 2, nk - 2);                              // past the end: re-fetch the last pair (unused)
+            loadA(k, 1, fa[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            comp(0, fa[0], fb[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            loadB(k + 1, fb[1]);
+            loadA(k + 1, 0, fa[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            comp(1, fa[1], fb[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            loadA(k + 1, 1, fa[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            comp(0, fa[0], fb[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            loadB(k2, fb[0]);
+            loadA(k2, 0, fa[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            comp(1, fa[1], fb[1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
-
-    if (dbg) {            // timing experiment: main loop only
+    if (dbg & 1) {            // timing experiment: main loop only
         float sum = 0.f;
-        for (int pi = 0; pi < PPW; ++pi) for (int e = 0; e < 16; ++e) sum += acc[pi][e];
+        for (int pi = 0; pi < PPW; ++pi) for (int bi = 0; bi < MB; ++bi) for (int e = 0; e < 16; ++e) sum += acc[pi][bi][e];
         if (sum == 12345.f) p.y[t] = sum;
         return;
     }
-    // ---- epilogue: all 36 positions of the workgroup's 32 x 32 (tile, channel) pairs meet in LDS, Y = A^T M A
-#pragma unroll
-    for (int pi = 0; pi < PPW; ++pi)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            smem[((pos0 + pi) * W4T + (r & 3) + 8 * (r >> 2) + 4 * h) * W4N + l31] = acc[pi][r];
-    __syncthreads();
+
+    // ---- epilogue, 32 tiles at a time: all 36 positions of 32 x 32 (tile, channel) pairs meet in LDS, Y = A^T M A
     const int n_l = t & 31, tsub = t >> 5;                                    // thread -> (channel, tiles tsub, tsub + 24)
     const int tpi = p.TH * p.TW, ohw = p.OH * p.OW;
     const int n = tn * W4N + n_l;
     const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int half = 0; half < MB; ++half) {
+        if (half) __syncthreads();
+#pragma unroll
+        for (int pi = 0; pi < PPW; ++pi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                smem[((pos0 + pi) * W4T + (r & 3) + 8 * (r >> 2) + 4 * h) * W4N + l31] = acc[pi][half][r];
+        __syncthreads();
 #pragma unroll 1
-    for (int q = 0; q < 2; ++q) {
-        const int tl = tsub + 24 * q;
-        if (tl >= W4T) break;
-        const long gt = (long)tm * W4T + tl;
-        if (gt >= p.Mt) continue;
-        const int b = fastdiv((int)gt, p.fd_tpi);
-        const int rr = (int)(gt - (long)b * tpi);
-        const int ty = fastdiv(rr, p.fd_tw), tx = rr - ty * p.TW;
-        // rows of M are the vertical index xi: pos = 6 xi + nu.  First the transform along nu (6 -> 4 per xi), then along xi.
-        float z[6][4];
+        for (int q = 0; q < 2; ++q) {
+            const int tl = tsub + 24 * q;
+            if (tl >= W4T) break;
+            const long gt = (long)tm * WT + 32 * half + tl;
+            if (gt >= p.Mt) continue;
+            const int b = fastdiv((int)gt, p.fd_tpi);
+            const int rr = (int)(gt - (long)b * tpi);
+            const int ty = fastdiv(rr, p.fd_tw), tx = rr - ty * p.TW;
+            // rows of M are the vertical index xi: pos = 6 xi + nu.  First the transform along nu (6 -> 4 per xi), then along xi.
+            float z[6][4];
 #pragma unroll
-        for (int xi = 0; xi < 6; ++xi) {
-            float m[6];
+            for (int xi = 0; xi < 6; ++xi) {
+                float m[6];
 #pragma unroll
-            for (int nu = 0; nu < 6; ++nu) m[nu] = smem[((xi * 6 + nu) * W4T + tl) * W4N + n_l];
-            const float s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
-            z[xi][0] = m[0] + s12 + s34;
-            z[xi][1] = d12 * 0.75f + d34 * 1.5f;
-            z[xi][2] = s12 * 0.5625f + s34 * 2.25f;
-            z[xi][3] = d12 * 0.421875f + d34 * 3.375f + m[5];            // 27/64, 27/8
-        }
-        const float *resb = p.res ? p.res + (long)(p.res_bmod ? b % p.res_bmod : b) * p.res_bs + n : nullptr;
-        float *yb = p.y + (p.y_bs ? (long)b * p.y_bs : (long)b * ohw * p.N) + n;
+                for (int nu = 0; nu < 6; ++nu) m[nu] = smem[((xi * 6 + nu) * W4T + tl) * W4N + n_l];
+                const float s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+                z[xi][0] = m[0] + s12 + s34;
+                z[xi][1] = d12 * 0.75f + d34 * 1.5f;
+                z[xi][2] = s12 * 0.5625f + s34 * 2.25f;
+                z[xi][3] = d12 * 0.421875f + d34 * 3.375f + m[5];            // 27/64, 27/8
+            }
+            const float *resb = p.res ? p.res + (long)(p.res_bmod ? b % p.res_bmod : b) * p.res_bs + n : nullptr;
+            float *yb = p.y + (p.y_bs ? (long)b * p.y_bs : (long)b * ohw * p.N) + n;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float s12 = z[1][j] + z[2][j], d12 = z[1][j] - z[2][j], s34 = z[3][j] + z[4][j], d34 = z[3][j] - z[4][j];
-            const float yv[4] = {z[0][j] + s12 + s34, d12 * 0.75f + d34 * 1.5f, s12 * 0.5625f + s34 * 2.25f,
-                                 d12 * 0.421875f + d34 * 3.375f + z[5][j]};
-            const int ow = 4 * tx + j;
-            if (ow >= p.OW) continue;
+            for (int j = 0; j < 4; ++j) {
+                const float s12 = z[1][j] + z[2][j], d12 = z[1][j] - z[2][j], s34 = z[3][j] + z[4][j], d34 = z[3][j] - z[4][j];
+                const float yv[4] = {z[0][j] + s12 + s34, d12 * 0.75f + d34 * 1.5f, s12 * 0.5625f + s34 * 2.25f,
+                                     d12 * 0.421875f + d34 * 3.375f + z[5][j]};
+                const int ow = 4 * tx + j;
+                if (ow >= p.OW) continue;
 #pragma unroll
-            for (int i2 = 0; i2 < 4; ++i2) {
-                const int oh = 4 * ty + i2;
-                if (oh >= p.OH) continue;
-                const long po = ((long)oh * p.OW + ow) * p.N;
-                float v = yv[i2] + bv;
-                if (resb) v += resb[po];
-                if (p.relu_out) v = fmaxf(v, 0.f);
-                yb[po] = v;
+                for (int i2 = 0; i2 < 4; ++i2) {
+                    const int oh = 4 * ty + i2;
+                    if (oh >= p.OH) continue;
+                    const int po = (oh * p.OW + ow) * p.N;
+                    float v = yv[i2] + bv;
+                    if (resb) v += resb[po];
+                    if (p.relu_out) v = fmaxf(v, 0.f);
+                    yb[po] = v;
+                }
             }
         }
     }
@@ -258,7 +333,7 @@ size_t wino4_workspace_floats(const ConvP &p, int min_wg) {
     if (!wino4_mode() || !p.wino4_u || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.x1) return 0;
     if (p.Cin % 32 || p.Cin < 128 || p.N % W4N || p.bs0 == 0) return 0;
     const long Mt = (long)p.B * ((p.OH + 3) / 4) * ((p.OW + 3) / 4);
-    const long Mt_pad = (Mt + W4T - 1) / W4T * W4T;
+    const long Mt_pad = (Mt + 2 * W4T - 1) / (2 * W4T) * (2 * W4T);          // whole 64-tile workgroup tiles
     if (36L * p.Cin * Mt_pad * 4 >= (1L << 32)) return 0;                   // 32-bit buffer offsets
     if (wino4_mode() < 2 && (Mt_pad / W4T) * (p.N / W4N) < min_wg) return 0;  // too few workgroups: F(2x2) with its split-K is better
     return (size_t)36 * p.Cin * Mt_pad;
@@ -266,7 +341,7 @@ size_t wino4_workspace_floats(const ConvP &p, int min_wg) {
 
 void wino4_launch(const ConvP &p, float *V, hipStream_t s, hipEvent_t *ev_in, hipEvent_t *ev_gemm) {
     const int TH = (p.OH + 3) / 4, TW = (p.OW + 3) / 4;
-    const int Mt = p.B * TH * TW, Mt_pad = (Mt + W4T - 1) / W4T * W4T, KB = p.Cin / 8;
+    const int Mt = p.B * TH * TW, Mt_pad = (Mt + 2 * W4T - 1) / (2 * W4T) * (2 * W4T), KB = p.Cin / 8;
     {
         const unsigned gx = (unsigned)((8L * Mt_pad + 255) / 256);
         const int NCB = p.Cin / 32;
@@ -288,16 +363,28 @@ void wino4_launch(const ConvP &p, float *V, hipStream_t s, hipEvent_t *ev_in, hi
     g.Mt = Mt; g.Mt_pad = Mt_pad; g.KB = KB; g.N = p.N;
     g.TH = TH; g.TW = TW; g.OH = p.OH; g.OW = p.OW; g.B = p.B; g.M = p.M;
     g.bias = p.bias; g.res = p.res; g.res_bs = p.res_bs; g.res_bmod = p.res_bmod; g.y = p.y; g.y_bs = p.y_bs; g.relu_out = p.relu_out;
-    const int tiles_m = Mt_pad / W4T, tiles_n = p.N / W4N;
+    // 64-tile workgroups (25 % fewer L2 bytes per MFMA: +6 % at 1/4 and 1/8 scale) unless they would leave CUs idle
+    static const int mb_env = [] { const char *e = getenv("STCN_WINO4_MB"); return e ? atoi(e) : 0; }();
+    const int tiles_n = p.N / W4N;
+    const int mb = mb_env == 1 || mb_env == 2 ? mb_env : ((Mt_pad / (2 * W4T)) * tiles_n >= 200 ? 2 : 1);
+    const int tiles_m = Mt_pad / (W4T * mb);
     g.fd_tpi = fastdiv_make((unsigned)(TH * TW)); g.fd_tw = fastdiv_make((unsigned)TW); g.fd_tiles_n = fastdiv_make((unsigned)tiles_n);
     const char *dbg_s = getenv("STCN_W4_DBG");
     const int dbg = dbg_s ? atoi(dbg_s) : 0;
     const size_t lds = (size_t)36 * W4T * W4N * sizeof(float);
-    allow_big_lds(reinterpret_cast<const void *>(&wino4_gemm_kernel), lds);
-    if (ev_gemm)
-        hipExtLaunchKernelGGL(wino4_gemm_kernel, dim3(tiles_m * tiles_n), dim3(64 * W4W), lds, s, ev_gemm[0], ev_gemm[1], 0, g, tiles_n, dbg);
-    else
-        hipLaunchKernelGGL(wino4_gemm_kernel, dim3(tiles_m * tiles_n), dim3(64 * W4W), lds, s, g, tiles_n, dbg);
+    if (mb == 2) {
+        allow_big_lds(reinterpret_cast<const void *>(&wino4_gemm_kernel<2>), lds);
+        if (ev_gemm)
+            hipExtLaunchKernelGGL(wino4_gemm_kernel<2>, dim3(tiles_m * tiles_n), dim3(64 * W4W), lds, s, ev_gemm[0], ev_gemm[1], 0, g, tiles_n, dbg);
+        else
+            hipLaunchKernelGGL(wino4_gemm_kernel<2>, dim3(tiles_m * tiles_n), dim3(64 * W4W), lds, s, g, tiles_n, dbg);
+    } else {
+        allow_big_lds(reinterpret_cast<const void *>(&wino4_gemm_kernel<1>), lds);
+        if (ev_gemm)
+            hipExtLaunchKernelGGL(wino4_gemm_kernel<1>, dim3(tiles_m * tiles_n), dim3(64 * W4W), lds, s, ev_gemm[0], ev_gemm[1], 0, g, tiles_n, dbg);
+        else
+            hipLaunchKernelGGL(wino4_gemm_kernel<1>, dim3(tiles_m * tiles_n), dim3(64 * W4W), lds, s, g, tiles_n, dbg);
+    }
 }
 
 // U [36][Cin/8][N][8] from the BN-folded direct weights w [N][Kp] (k = (ky*3 + kx) * Cin + c), on the host in double;
