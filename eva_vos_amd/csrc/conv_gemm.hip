@@ -373,34 +373,55 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvP p, const int
                 const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (unsigned)((long)p.M * p.N * 4), 0x00020000);
                 const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.res ? p.res : p.y), 0, (unsigned)((long)p.M * p.N * 4), 0x00020000);
                 const unsigned v0 = (unsigned)(((long)mbase * p.N + n) * 4), n4 = (unsigned)p.N * 4u;
+                // rows >= M lie at >= M*N*4 bytes, beyond the descriptor range (no wrap: (M + 128) * N * 4 < 4 GiB, run_conv).
+                // The 16 residual values are requested TOGETHER, before the first use: with the load behind `if (p.res)` inside the
+                // loop hipcc waited vmcnt(0) per element - 16 serialized round trips per accumulator block, longer than the
+                // 8-K-tile MFMA body of the ResNet 1x1 convs that carry the residual.
+                float rv[16];
+                if (p.res) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, v0 + (unsigned)((r & 3) + 8 * (r >> 2)) * n4, 0, 0));
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+                }
+                const float lo = p.relu_out ? 0.f : -__builtin_inff();
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    // rows >= M lie at >= M*N*4 bytes, beyond the descriptor range (no wrap: (M + 128) * N * 4 < 4 GiB, run_conv)
                     const unsigned vo = v0 + (unsigned)((r & 3) + 8 * (r >> 2)) * n4;
-                    float v = c[r] + bv;
-                    if (p.res) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, vo, 0, 0));
-                    if (p.relu_out) v = fmaxf(v, 0.f);
+                    const float v = fmaxf(c[r] + bv + rv[r], lo);
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, vo, 0, 0);
                 }
                 continue;
             }
+            // general layout (batch strides / broadcast residual): addresses first, then all residual loads, then the stores
             const bool needb = p.res != nullptr || p.y_bs != 0;
+            long yo[16], ro[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = mbase + (r & 3) + 8 * (r >> 2);
-                if (m < p.M) {
-                    float v = c[r] + bv;
-                    long yo = (long)m * p.N + n;
-                    if (needb) {
-                        const int b = p.B == 1 ? 0 : fastdiv(m, p.fd_ohw);
-                        const long po = (long)(m - b * ohw) * p.N + n;
-                        if (p.res) v += p.res[(long)(p.res_bmod ? b % p.res_bmod : b) * p.res_bs + po];
-                        if (p.y_bs) yo = (long)b * p.y_bs + po;
-                    }
-                    if (p.relu_out) v = fmaxf(v, 0.f);
-                    p.y[yo] = v;
+                const int m = min(mbase + (r & 3) + 8 * (r >> 2), p.M - 1);          // rows beyond M: clamped here, not stored below
+                yo[r] = (long)m * p.N + n;
+                ro[r] = 0;
+                if (needb) {
+                    const int b = p.B == 1 ? 0 : fastdiv(m, p.fd_ohw);
+                    const long po = (long)(m - b * ohw) * p.N + n;
+                    ro[r] = (long)(p.res_bmod ? b % p.res_bmod : b) * p.res_bs + po;
+                    if (p.y_bs) yo[r] = (long)b * p.y_bs + po;
                 }
             }
+            float rv[16];
+            if (p.res) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rv[r] = p.res[ro[r]];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+            }
+            const float lo = p.relu_out ? 0.f : -__builtin_inff();
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (mbase + (r & 3) + 8 * (r >> 2) < p.M) p.y[yo[r]] = fmaxf(c[r] + bv + rv[r], lo);
         }
 }
 
@@ -651,26 +672,31 @@ __global__ __launch_bounds__(256) void conv_n1_kernel(const float *__restrict__ 
     if (valid && sub == 0) y[pixel] = acc + bias;
 }
 
-// Cout == 1, 3x3, C == 256 (decoder.pred): one wave = 8 consecutive pixels of a row, lane = 4 channels of every pixel.  The wave
-// loads its 3 x 10 input pixels ONCE (16 B per lane each) and keeps its 36 weights in registers; the 4 waves of a workgroup
-// take 4 consecutive rows of the same column strip, so two of a wave's three input rows are its neighbours' too (L1).
-// The first version (one wave per pixel, 9 KB through L2 per output) fetched 4.3x the input: 572 MB for 133 MB.
+// Cout == 1, 3x3 (decoder.pred: C = 256; FusionNet.final_conv: C = 32).  LPP = C / 4 lanes hold the channels of a pixel (4 each); a
+// group of LPP lanes computes 8 consecutive pixels of a row: it loads its 3 x 10 input pixels ONCE (16 B per lane each) and keeps
+// its 36 weights in registers; a wave holds 64 / LPP such groups side by side (64 pixels of the row at C = 32), the 4 waves of a
+// workgroup take 4 consecutive rows of the same column strip, so two of a wave's three input rows are its neighbours' too (L1).
+// The first versions (one wave / one 8-lane group per pixel, 9 taps fetched per output) pulled 4.3x the input through L2; a
+// `if (relu_in)` branch behind every load then made hipcc drain vmcnt per load (30 serialized round trips per strip): ReLU is
+// max(v, lo) with lo = 0 or -inf now.
+template <int C>
 __global__ __launch_bounds__(256) void conv_n1_strip_kernel(const float *__restrict__ x, const float *__restrict__ w, float bias,
                                                             float *__restrict__ y, int B, int H, int W, int relu_in) {
-    constexpr int C = 256, PX = 8;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int strips = (W + PX - 1) / PX, rows4 = (H + 3) / 4;
+    constexpr int PX = 8, LPP = C / 4, NS = 64 / LPP;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sl = lane % LPP, sub = lane / LPP;
+    const int strips = (W + PX * NS - 1) / (PX * NS), rows4 = (H + 3) / 4;
     const int sx = blockIdx.x % strips;
     const int ry = (blockIdx.x / strips) % rows4, b = blockIdx.x / (strips * rows4);
-    const int oy = ry * 4 + wave, ox0 = sx * PX;
+    const int oy = ry * 4 + wave, ox0 = (sx * NS + sub) * PX;
     if (oy >= H) return;
+    const float lo = relu_in ? 0.f : -__builtin_inff();
     f32x4 wt[9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const f32x4 *>(w + t * C + 4 * lane);
+    for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const f32x4 *>(w + t * C + 4 * sl);
     float acc[PX];
 #pragma unroll
     for (int i = 0; i < PX; ++i) acc[i] = 0.f;
-    const float *xb = x + (long)b * H * W * C + 4 * lane;
+    const float *xb = x + (long)b * H * W * C + 4 * sl;
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
         const int iy = oy + kh - 1;
@@ -681,7 +707,7 @@ __global__ __launch_bounds__(256) void conv_n1_strip_kernel(const float *__restr
             const int ix = ox0 + j - 1;
             f32x4 u = {0.f, 0.f, 0.f, 0.f};
             if ((unsigned)ix < (unsigned)W) u = *reinterpret_cast<const f32x4 *>(xb + ((long)iy * W + ix) * C);
-            if (relu_in) { u.x = fmaxf(u.x, 0.f); u.y = fmaxf(u.y, 0.f); u.z = fmaxf(u.z, 0.f); u.w = fmaxf(u.w, 0.f); }
+            u.x = fmaxf(u.x, lo); u.y = fmaxf(u.y, lo); u.z = fmaxf(u.z, lo); u.w = fmaxf(u.w, lo);
             v[j] = u;
         }
 #pragma unroll
@@ -697,12 +723,12 @@ __global__ __launch_bounds__(256) void conv_n1_strip_kernel(const float *__restr
 #pragma unroll
     for (int i = 0; i < PX; ++i)
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) acc[i] += __shfl_xor(acc[i], o);
-    if (lane < PX && ox0 + lane < W) {
+        for (int o = LPP / 2; o > 0; o >>= 1) acc[i] += __shfl_xor(acc[i], o);
+    if (sl < PX && ox0 + sl < W) {
         float r = acc[0];
 #pragma unroll
-        for (int i = 1; i < PX; ++i) r = lane == i ? acc[i] : r;
-        y[((long)b * H + oy) * W + ox0 + lane] = r + bias;
+        for (int i = 1; i < PX; ++i) r = sl == i ? acc[i] : r;
+        y[((long)b * H + oy) * W + ox0 + sl] = r + bias;
     }
 }
 
@@ -711,7 +737,12 @@ void conv_n1_launch(const float *x, const float *w, float bias, float *y, int B,
     const long npix = (long)B * H * W;
     if (C == 256 && KH == 3) {
         const unsigned blocks = (unsigned)((long)B * ((H + 3) / 4) * ((W + 7) / 8));
-        hipLaunchKernelGGL(conv_n1_strip_kernel, dim3(blocks), dim3(256), 0, s, x, w, bias, y, B, H, W, relu_in);
+        hipLaunchKernelGGL(conv_n1_strip_kernel<256>, dim3(blocks), dim3(256), 0, s, x, w, bias, y, B, H, W, relu_in);
+        return;
+    }
+    if (C == 32 && KH == 3) {
+        const unsigned blocks = (unsigned)((long)B * ((H + 3) / 4) * ((W + 63) / 64));
+        hipLaunchKernelGGL(conv_n1_strip_kernel<32>, dim3(blocks), dim3(256), 0, s, x, w, bias, y, B, H, W, relu_in);
         return;
     }
     if (C >= 256) {

@@ -143,12 +143,17 @@ __global__ __launch_bounds__(256, 2) void fusion_conv_kernel(const float *__rest
             const int oy = y0 + wave * RB + b;
             if (oy >= H) continue;
             const long rowo = ((long)oy * W + x0) * 32 + l31;
+            float rv[16];                                                     // residual: all 16 loads in flight before the first use
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int px = min((r & 3) + 8 * (r >> 2) + 4 * h, W - 1 - x0);
+                rv[r] = HAS_RES ? res[rowo + px * 32] : 0.f;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int px = (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (x0 + px >= W) continue;
-                float v = acc[b][r] + bv;
-                if (HAS_RES) v += res[rowo + px * 32];
+                float v = acc[b][r] + bv + rv[r];
                 if (RELU_OUT) v = fmaxf(v, 0.f);
                 y[rowo + px * 32] = v;
             }

@@ -251,21 +251,25 @@ __global__ __launch_bounds__(1024 / PPW) void wino_gemm_kernel(const WinoG p, co
             const float *resb = p.res ? p.res + (long)(p.res_bmod ? b % p.res_bmod : b) * p.res_bs + n : nullptr;
             float *yb = p.splitk > 1 ? p.partial + ((long)split * p.M + (long)b * ohw) * p.N + n
                                      : p.y + (p.y_bs ? (long)b * p.y_bs : (long)b * ohw * p.N) + n;
+            // offsets (clamped inside the image for the ragged last tile row / column), then the 4 residual values TOGETHER (a load
+            // behind `if (resb)` per output made hipcc drain vmcnt per element), then the stores
+            long po[4];
+            float rv[4];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int e = 0; e < 4; ++e) po[e] = ((long)min(toh[q] + (e >> 1), p.OH - 1) * p.OW + min(tow[q] + (e & 1), p.OW - 1)) * p.N;
+            if (resb && p.splitk == 1) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int oh = toh[q] + i, ow = tow[q] + j;
-                    if (oh >= p.OH || ow >= p.OW) continue;
-                    const long po = ((long)oh * p.OW + ow) * p.N;
-                    float v = yv[i][j];
-                    if (p.splitk == 1) {
-                        v += bv;
-                        if (resb) v += resb[po];
-                        if (p.relu_out) v = fmaxf(v, 0.f);
-                    }
-                    yb[po] = v;
-                }
+                for (int e = 0; e < 4; ++e) rv[e] = resb[po[e]];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rv[e] = 0.f;
+            }
+            const float lo = (p.relu_out && p.splitk == 1) ? 0.f : -__builtin_inff();
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (toh[q] + (e >> 1) >= p.OH || tow[q] + (e & 1) >= p.OW) continue;
+                yb[po[e]] = fmaxf(yv[e >> 1][e & 1] + (p.splitk == 1 ? bv : 0.f) + rv[e], lo);
+            }
         }
     }
 }

@@ -300,23 +300,35 @@ __global__ __launch_bounds__(64 * W4W) void wino4_gemm_kernel(const Wino4G p, co
             }
             const float *resb = p.res ? p.res + (long)(p.res_bmod ? b % p.res_bmod : b) * p.res_bs + n : nullptr;
             float *yb = p.y + (p.y_bs ? (long)b * p.y_bs : (long)b * ohw * p.N) + n;
+            // the 16 residual values of the tile are requested TOGETHER, before the column transform (a load behind `if (resb)`
+            // per output made hipcc drain vmcnt per element); ragged tiles: offsets clamped inside the image, stores masked
+            float rv[4][4];
+            int po[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i2 = 0; i2 < 4; ++i2) po[j][i2] = (min(4 * ty + i2, p.OH - 1) * p.OW + min(4 * tx + j, p.OW - 1)) * p.N;
+            if (resb) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i2 = 0; i2 < 4; ++i2) rv[j][i2] = resb[po[j][i2]];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i2 = 0; i2 < 4; ++i2) rv[j][i2] = 0.f;
+            }
+            const float lo = p.relu_out ? 0.f : -__builtin_inff();
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float s12 = z[1][j] + z[2][j], d12 = z[1][j] - z[2][j], s34 = z[3][j] + z[4][j], d34 = z[3][j] - z[4][j];
                 const float yv[4] = {z[0][j] + s12 + s34, d12 * 0.75f + d34 * 1.5f, s12 * 0.5625f + s34 * 2.25f,
                                      d12 * 0.421875f + d34 * 3.375f + z[5][j]};
-                const int ow = 4 * tx + j;
-                if (ow >= p.OW) continue;
+                if (4 * tx + j >= p.OW) continue;
 #pragma unroll
-                for (int i2 = 0; i2 < 4; ++i2) {
-                    const int oh = 4 * ty + i2;
-                    if (oh >= p.OH) continue;
-                    const int po = (oh * p.OW + ow) * p.N;
-                    float v = yv[i2] + bv;
-                    if (resb) v += resb[po];
-                    if (p.relu_out) v = fmaxf(v, 0.f);
-                    yb[po] = v;
-                }
+                for (int i2 = 0; i2 < 4; ++i2)
+                    if (4 * ty + i2 < p.OH) yb[po[j][i2]] = fmaxf(yv[i2] + bv + rv[j][i2], lo);
             }
         }
     }

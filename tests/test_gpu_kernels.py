@@ -27,6 +27,7 @@ CONVS = [
     (1, 15, 27, 1280, 512, 3, 1, 1, 0),     # fuser-like big K, relu in, auto split
     (1, 30, 54, 256, 1, 3, 1, 1, 0),        # decoder.pred (Cout 1), relu in
     (1, 40, 56, 32, 1, 3, 1, 0, 0),         # fusion final_conv (Cout 1)
+    (1, 21, 150, 32, 1, 3, 1, 1, 0),        # ... three 64-pixel strips, ragged rows and columns, ReLU on the input
     # more than one round of tiles: the plan balances the tail (whole rounds unsplit + K pieces of the last tiles)
     (2, 67, 65, 64, 256, 3, 1, 3, 0),       # 548 tiles = 512 + 36 x 4 pieces; ragged last tile, batch 2, residual, relus
     (1, 184, 192, 64, 32, 3, 1, 2, 0),      # narrow tiles: 276 = 256 + 20 x 4 pieces
