@@ -418,10 +418,15 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvP p, const int
 #pragma unroll
                 for (int r = 0; r < 16; ++r) rv[r] = 0.f;
             }
+            // every value first (ONE wait for the residual loads), then the masked stores: with the arithmetic inside the masked
+            // blocks hipcc put a vmcnt(0) in front of each, which also waits for the previous block's STORE
             const float lo = p.relu_out ? 0.f : -__builtin_inff();
+            float ov[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { ov[r] = fmaxf(c[r] + bv + rv[r], lo); asm volatile("" : "+v"(ov[r])); }   // pinned: hipcc sinks it into the masked blocks otherwise
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                if (mbase + (r & 3) + 8 * (r >> 2) < p.M) p.y[yo[r]] = fmaxf(c[r] + bv + rv[r], lo);
+                if (mbase + (r & 3) + 8 * (r >> 2) < p.M) p.y[yo[r]] = ov[r];
         }
 }
 

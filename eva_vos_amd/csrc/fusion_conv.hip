@@ -151,11 +151,14 @@ __global__ __launch_bounds__(256, 2) void fusion_conv_kernel(const float *__rest
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
+                rv[r] += acc[b][r] + bv;
+                if (RELU_OUT) rv[r] = fmaxf(rv[r], 0.f);
+                asm volatile("" : "+v"(rv[r]));                                 // pinned in front of the masked stores
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
                 const int px = (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (x0 + px >= W) continue;
-                float v = acc[b][r] + bv + rv[r];
-                if (RELU_OUT) v = fmaxf(v, 0.f);
-                y[rowo + px * 32] = v;
+                if (x0 + px < W) y[rowo + px * 32] = rv[r];
             }
         }
     }

@@ -265,10 +265,13 @@ __global__ __launch_bounds__(1024 / PPW) void wino_gemm_kernel(const WinoG p, co
                 for (int e = 0; e < 4; ++e) rv[e] = 0.f;
             }
             const float lo = (p.relu_out && p.splitk == 1) ? 0.f : -__builtin_inff();
+            float ov[4];                                                  // values first (one wait), masked stores after
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { ov[e] = fmaxf(yv[e >> 1][e & 1] + (p.splitk == 1 ? bv : 0.f) + rv[e], lo); asm volatile("" : "+v"(ov[e])); }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (toh[q] + (e >> 1) >= p.OH || tow[q] + (e & 1) >= p.OW) continue;
-                yb[po[e]] = fmaxf(yv[e >> 1][e & 1] + (p.splitk == 1 ? bv : 0.f) + rv[e], lo);
+                yb[po[e]] = ov[e];
             }
         }
     }

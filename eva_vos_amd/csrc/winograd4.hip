@@ -325,10 +325,15 @@ __global__ __launch_bounds__(64 * W4W) void wino4_gemm_kernel(const Wino4G p, co
                 const float s12 = z[1][j] + z[2][j], d12 = z[1][j] - z[2][j], s34 = z[3][j] + z[4][j], d34 = z[3][j] - z[4][j];
                 const float yv[4] = {z[0][j] + s12 + s34, d12 * 0.75f + d34 * 1.5f, s12 * 0.5625f + s34 * 2.25f,
                                      d12 * 0.421875f + d34 * 3.375f + z[5][j]};
+#pragma unroll
+                for (int i2 = 0; i2 < 4; ++i2) { rv[j][i2] = fmaxf(yv[i2] + bv + rv[j][i2], lo); asm volatile("" : "+v"(rv[j][i2])); }   // values first, pinned
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                                     // masked stores after the one wait for the residual loads
                 if (4 * tx + j >= p.OW) continue;
 #pragma unroll
                 for (int i2 = 0; i2 < 4; ++i2)
-                    if (4 * ty + i2 < p.OH) yb[po[j][i2]] = fmaxf(yv[i2] + bv + rv[j][i2], lo);
+                    if (4 * ty + i2 < p.OH) yb[po[j][i2]] = rv[j][i2];
             }
         }
     }
