@@ -11,8 +11,9 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof_final")
 DST = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
-GEMM = ("conv_gemm_kernel", "wino_gemm_kernel")          # the fp32-MFMA conv GEMMs (the roofline's dominant kernels)
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+commit = sys.argv[2] if len(sys.argv) > 2 else "unknown"      # the commit the GPU box ran (the snapshot has no .git)
+GEMM = ("conv_gemm_kernel", "wino_gemm_kernel", "wino4_gemm_kernel", "fusion_conv_kernel")   # the fp32-MFMA conv GEMMs (the roofline's dominant kernels)
 
 
 def last_json(path):
@@ -47,7 +48,7 @@ frames = trace_bench["config"]["frames_per_step"] * (trace_bench["steps"] + trac
 gemm = [r for r in stats if any(g in r["Name"] for g in GEMM)]
 calls = sum(int(r["Calls"]) for r in gemm)
 ns = sum(float(r["TotalDurationNs"]) for r in gemm)
-wi = [r for r in stats if "wino_input_kernel" in r["Name"]]
+wi = [r for r in stats if "_input_kernel" in r["Name"] and "wino" in r["Name"]]
 wi_ns = sum(float(r["TotalDurationNs"]) for r in wi)
 rd_ns = sum(float(r["TotalDurationNs"]) for r in stats if "conv_reduce" in r["Name"])
 lines = [f"# rocprofv3 --kernel-trace --stats - {tag}, final engine of the round (solo launches)", "",
@@ -60,7 +61,7 @@ lines = [f"# rocprofv3 --kernel-trace --stats - {tag}, final engine of the round
 for r in stats[:24]:
     lines.append(f"| {short(r['Name'])} | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.1f} | {float(r['AverageNs']) / 1e3:.1f} | {r['Percentage']} |")
 ex, al = roof["executed_flop_per_launch_avg"], roof["algorithmic_flop_per_launch_avg"]
-lines += ["", f"Conv GEMMs (conv_gemm_kernel all variants + wino_gemm_kernel): {calls} launches, {ns / 1e6:.1f} ms, average {ns / calls / 1e3:.2f} us per launch; "
+lines += ["", f"Conv GEMMs (conv_gemm_kernel all variants + wino_gemm_kernel + wino4_gemm_kernel): {calls} launches, {ns / 1e6:.1f} ms, average {ns / calls / 1e3:.2f} us per launch; "
           f"with {ex / 1e9:.3f} GFLOP executed / {al / 1e9:.3f} GFLOP algorithmic per launch on average (bench roofline leg) = "
           f"{ex / (ns / calls * 1e-9) / 1e12:.1f} TFLOP/s executed on the matrix cores.",
           f"Including the Winograd input transforms ({wi_ns / 1e6:.1f} ms) and split-K reduces ({rd_ns / 1e6:.1f} ms): "
@@ -87,6 +88,46 @@ if td:
         f"kernel's solo duration: while three conv kernels share the chip each one takes longer.  The roofline uses solo launches "
         f"(roofline leg avg {bd['roofline']['avg_launch_ms'] * 1e3:.2f} us = the `--streams 1` trace in "
         f"`{tag}_bench_streams1_kernel_stats.md`).\n\nFull table: `{tag}_bench_default_kernel_stats.csv`.\n")
+
+# ---- rounds 2..8 of an annotation session: trace of eight rounds minus trace of the first round alone
+t2, t1 = stats_csv("trace_r2"), stats_csv("trace_r1")
+if t2 and t1:
+    a = {r["Name"]: (int(r["Calls"]), float(r["TotalDurationNs"])) for r in csv.DictReader(open(t2))}
+    b = {r["Name"]: (int(r["Calls"]), float(r["TotalDurationNs"])) for r in csv.DictReader(open(t1))}
+    rows = sorted(((t - b.get(k, (0, 0.0))[1], c - b.get(k, (0, 0.0))[0], k) for k, (c, t) in a.items()), reverse=True)
+    rows = [r for r in rows if r[1] > 0]
+    tot2 = sum(r[0] for r in rows)
+    with open(os.path.join(DST, f"{tag}_r2_kernel_stats.csv"), "w") as f:
+        f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage\n")
+        for t, c, k in rows:
+            f.write(f"\"{k}\",{c},{t:.0f},{t / c:.1f},{100 * t / tot2:.4f}\n")
+    txt = [l for l in open(os.path.join(SRC, "r2_profile.txt")).read().split("\n") if l.startswith("round") or l.startswith("rounds") or l.startswith("kernel time") or l.startswith("  ")]
+    frames2 = 184
+    md = [f"# Rounds 2..8 of an annotation session on one 66-frame 480x854 clip ({tag})", "",
+          "The regime the reference's loops spend their time in (7 of the 8 rounds of interactions/mask.py:113-146, 59 of 60 of eval_annotation_method.py:30): "
+          "cached key features, memory read + decoder on every frame, FusionNet + attention read on the frames between interacted frames, a value encode "
+          "every 5th frame.", "",
+          "Commands (GPU box): `rocprofv3 --kernel-trace --stats -- python3 tools/r2_profile.py --no-class-profile` (8 rounds) and `... --rounds 1`; "
+          "the table is the difference of the two kernel-stat tables = rounds 2..8 alone (184 propagated frames).", "",
+          f"Total kernel time {tot2 / 1e6:.1f} ms = {tot2 / 1e6 / frames2:.3f} ms per propagated frame.", "",
+          "| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
+    for t, c, k in rows[:26]:
+        md.append(f"| {short(k)} | {c} | {t / 1e6:.2f} | {t / c / 1e3:.1f} | {100 * t / tot2:.2f} |")
+    md += ["", "Per launch class, HIP events (`python tools/r2_profile.py`, second pass):", "", "```"] + txt + ["```"]
+    r2 = bench.get("roofline_r2") or {}
+    if r2:
+        md += ["", f"bench.py `roofline_r2` of the same build (interact(mask, T//2) after interact(mask, 0)): {r2.get('frames_per_s_solo', 0):.0f} frames/s one video in flight, "
+               f"{r2.get('frames_per_s_videos_in_flight', 0):.0f} with videos in flight; conv GEMMs (decoder + value encoder + FusionNet) {r2.get('achieved', 0):.1f} TFLOP/s executed = "
+               f"{r2.get('frac', 0):.3f} of the fp32 MFMA peak; FusionNet convs {r2.get('fusion_conv_tflops', 0):.1f} TFLOP/s, {r2.get('fusion_conv_ms_per_fused_frame', 0) * 1e3:.0f} us per fused frame."]
+    open(os.path.join(DST, f"{tag}_r2_kernel_stats.md"), "w").write("\n".join(md) + "\n")
+
+# ---- counters of the F(4x4) GEMM (tools/pmc_f4.sh)
+pf = os.path.join(SRC, "pmc_wino4.txt")
+if os.path.exists(pf):
+    open(os.path.join(DST, f"{tag}_pmc_wino4.txt"), "w").write(
+        "rocprofv3 --pmc passes (one counter set per pass, --kernel-trace only) of `STCN_BENCH_CONV_F4=1 python3 tools/conv_shapes.py --only \"256->256 @4\" --batch 5 --iters 3`\n"
+        "(the decoder's 256 -> 256 3x3 conv at 120x216 over a 5-frame decode group as Winograd F(4x4,3x3)); means per launch.  FETCH_SIZE / WRITE_SIZE in KB\n"
+        "(FETCH_SIZE x2 on gfx950 for 16 B/lane reads); GRBM_GUI_ACTIVE sums the 8 XCDs: / 8 / launch time = the clock the chip held.\n\n" + open(pf).read())
 
 # ---- memory-read bench trace
 tm = stats_csv("trace_memread")
@@ -125,9 +166,10 @@ for k in F:
 cg = [k for k in kernels if any(g in k for g in GEMM)]
 n = sum(kernels[k]["calls"] for k in cg)
 traffic = sum(kernels[k]["traffic_bytes_per_launch"] * kernels[k]["calls"] for k in cg) / n
-wk = [k for k in kernels if "wino_input_kernel" in k]
+wk = [k for k in kernels if "wino" in k and "_input_kernel" in k]
 out = dict(command="rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) --kernel-trace -- python3 bench.py --steps 1 --warmup 0 --streams 1 "
-                   "--no-profile --frames 30 --cpu-frames 0 --no-r2 --no-config3 --no-memread-roofline (STCN_LOOKAHEAD=0)",
+                   "--no-profile --frames 30 --cpu-frames 0 --no-r2 --no-config3 --no-memread-roofline --no-davis-val (STCN_LOOKAHEAD=0)",
+           commit=commit, frames=30, captured=f"{tag}, tools/refresh_profiles.sh",
            units="counter values are KB per the rocprofv3 derived metric; gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reads 1/2 of the "
                  "bytes of wide (16 B/lane) coalesced reads -> doubled; WRITE_SIZE exact; Infinity-Cache hits are included (fabric-side counters)",
            conv_gemm_traffic_bytes_per_launch=traffic, conv_gemm_launches=n,
