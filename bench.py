@@ -606,6 +606,9 @@ def main():
                 acc = prof.setdefault(cls, dict(ms=0.0, launches=0, flops=0.0, bytes=0.0, exec_flops=0.0))
                 for k_ in acc:
                     acc[k_] += v[k_]
+                if cls == "conv_hbm_bound":
+                    for k_ in ("wino2_flops", "wino4_flops"):
+                        acc[k_] = acc.get(k_, 0.0) + v[k_]
             del e
         os.environ["STCN_LOOKAHEAD"] = la_saved
 
@@ -698,16 +701,20 @@ def main():
             alg = conv["flops"] / (conv_all_ms * 1e-3) / 1e12 if conv_all_ms > 0 else 0.0
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-                               "kernel": "conv_gemm_kernel + wino_gemm_kernel (fp32 MFMA conv GEMMs, v_mfma_f32_32x32x2_f32)",
+                               "kernel": "conv_gemm_kernel + wino_gemm_kernel + wino4_gemm_kernel (fp32 MFMA conv GEMMs, v_mfma_f32_32x32x2_f32: direct "
+                                         "implicit GEMM, Winograd F(2x2,3x3), Winograd F(4x4,3x3) for the decoder side)",
                                "what": "executed MFMA FLOP of all conv GEMM launches / their summed device time (HIP events per launch)",
                                "launches": conv["launches"], "avg_launch_ms": conv["ms"] / max(conv["launches"], 1),
                                "executed_flop_per_launch_avg": conv["exec_flops"] / max(conv["launches"], 1),
                                "algorithmic_flop_per_launch_avg": conv["flops"] / max(conv["launches"], 1),
                                "algorithmic_tflops_incl_transforms": alg,
                                "algorithmic_frac_of_peak": alg / FP32_MFMA_PEAK_TFLOPS,
-                               "winograd_share_of_algorithmic_flop": 1.0 - (2.25 * conv["exec_flops"] - conv["flops"]) / (1.25 * conv["flops"]) if conv["flops"] > 0 else 0.0,
+                               "executed_over_algorithmic_flop": conv["exec_flops"] / conv["flops"] if conv["flops"] > 0 else 0.0,
                                "wino_input_transform_ms_share_of_conv": wi["ms"] / conv_all_ms if conv_all_ms > 0 else 0.0}
             hb = prof.pop("conv_hbm_bound")                      # subset of "conv": launches below 19.7 FLOP/B
+            if conv["flops"] > 0:
+                out["roofline"]["winograd_f2x2_share_of_algorithmic_flop"] = hb.get("wino2_flops", 0.0) / conv["flops"]
+                out["roofline"]["winograd_f4x4_share_of_algorithmic_flop"] = hb.get("wino4_flops", 0.0) / conv["flops"]
             tot_ms = sum(v["ms"] for v in prof.values())
             out["kernel_time_share"] = {c: round(v["ms"] / tot_ms, 4) for c, v in prof.items() if v["ms"] > 0}
             if hb["ms"] > 0 and conv["ms"] > hb["ms"]:

@@ -25,6 +25,7 @@ const char *get_error() { return g_err; }
 void Prof::reset() {
     for (int i = 0; i < STCN_K_COUNT; ++i) { flops[i] = 0; bytes[i] = 0; exec_flops[i] = 0; launches[i] = 0; }
     hbm_conv_flops = hbm_conv_bytes = hbm_conv_ms = 0; hbm_conv_launches = 0;
+    wino2_flops = wino4_flops = 0;
     for (auto &e : events) { pool.push_back(e.a); pool.push_back(e.b); }
     events.clear();
 }
@@ -382,6 +383,7 @@ int run_conv(const Model &m, Work &w, hipStream_t s, const char *name, const flo
         w.prof->flops[cls] += fl;
         w.prof->exec_flops[cls] += fl_exec;
         if (hbm_acc) { w.prof->hbm_conv_bytes += bytes; w.prof->hbm_conv_flops += fl; }
+        if (wino4) w.prof->wino4_flops += fl; else if (wino) w.prof->wino2_flops += fl;
         eg = w.prof->attach(cls, hbm_acc);
         if (wino4) {
             ei = w.prof->attach(STCN_K_WINO_INPUT);
@@ -1221,6 +1223,7 @@ int stcn_get_conv_regimes(stcn_engine *e, double *out) {
     float ms[STCN_K_COUNT];
     if (e->prof.on) { int rc = e->prof.collect(ms); if (rc) return rc; }
     out[0] = e->prof.hbm_conv_flops; out[1] = e->prof.hbm_conv_bytes; out[2] = e->prof.hbm_conv_ms; out[3] = e->prof.hbm_conv_launches;
+    out[4] = e->prof.wino2_flops; out[5] = e->prof.wino4_flops;
     return STCN_OK;
 }
 

@@ -75,6 +75,7 @@ struct Prof {
     hipEvent_t *attach(int cls, bool hbm_bound_conv = false);
     // conv launches below the machine balance (HBM-bound), also counted in the STCN_K_CONV totals
     double hbm_conv_flops = 0, hbm_conv_bytes = 0, hbm_conv_ms = 0; int hbm_conv_launches = 0;
+    double wino2_flops = 0, wino4_flops = 0;    // algorithmic FLOP of the convs that ran as Winograd F(2x2,3x3) / F(4x4,3x3)
     void end(hipStream_t s);
     int collect(float *ms);
     ~Prof();

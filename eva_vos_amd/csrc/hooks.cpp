@@ -110,11 +110,14 @@ int stcn_bench_conv(void *stream, int B, int H, int W, int Cin, int Cout, int KH
     w.splitk = ws.p;
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    DevBuf resb;                                                  // STCN_BENCH_CONV_RES=1: with a residual operand (the ResNet conv3 layers)
+    const long obs = (long)OH * OW * Cout;
+    if (getenv("STCN_BENCH_CONV_RES")) { RC(resb.alloc((size_t)B * obs)); HIPCHK(hipMemsetAsync(resb.p, 0, (size_t)B * obs * 4, s)); }
     for (int i = 0; i < 3; ++i)
-        RC(run_conv(m, w, s, "t", x.p, Cin, (long)H * W * Cin, nullptr, 0, 0, B, H, W, stride, y.p, 0, nullptr, 0, 0, 1, splitk));
+        RC(run_conv(m, w, s, "t", x.p, Cin, (long)H * W * Cin, nullptr, 0, 0, B, H, W, stride, y.p, 0, resb.p, resb.p ? obs : 0, 0, 1, splitk));
     HIPCHK(hipEventRecord(e0, s));
     for (int i = 0; i < iters; ++i)
-        RC(run_conv(m, w, s, "t", x.p, Cin, (long)H * W * Cin, nullptr, 0, 0, B, H, W, stride, y.p, 0, nullptr, 0, 0, 1, splitk));
+        RC(run_conv(m, w, s, "t", x.p, Cin, (long)H * W * Cin, nullptr, 0, 0, B, H, W, stride, y.p, 0, resb.p, resb.p ? obs : 0, 0, 1, splitk));
     HIPCHK(hipEventRecord(e1, s));
     HIPCHK(hipEventSynchronize(e1));
     float ms = 0.f;

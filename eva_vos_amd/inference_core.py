@@ -226,10 +226,11 @@ class InferenceCore:
         _lib.check(_lib.lib().stcn_get_kernel_bytes(self._engine, by))
         _lib.check(_lib.lib().stcn_get_kernel_exec_flops(self._engine, ex))
         out = {c: dict(ms=ms[i], launches=ln[i], flops=fl[i], bytes=by[i], exec_flops=ex[i]) for i, c in enumerate(_lib.K_CLASSES)}
-        reg = (C.c_double * 4)()
+        reg = (C.c_double * 6)()
         _lib.check(_lib.lib().stcn_get_conv_regimes(self._engine, reg))
         # conv launches below the machine balance (HBM-bound); a subset of the "conv" totals
-        out["conv_hbm_bound"] = dict(ms=reg[2], launches=int(reg[3]), flops=reg[0], bytes=reg[1], exec_flops=reg[0])
+        out["conv_hbm_bound"] = dict(ms=reg[2], launches=int(reg[3]), flops=reg[0], bytes=reg[1], exec_flops=reg[0],
+                                      wino2_flops=reg[4], wino4_flops=reg[5])
         return out
 
     def __deepcopy__(self, memo):

@@ -186,8 +186,9 @@ int stcn_get_kernel_bytes(const stcn_engine *e, double *bytes /*[STCN_K_COUNT]*/
 int stcn_get_kernel_exec_flops(const stcn_engine *e, double *flops /*[STCN_K_COUNT]*/);
 /* Conv launches of the last interact() whose arithmetic intensity (algorithmic FLOP / algorithmic bytes) lies below the
  * machine balance 157.3 TFLOP/s / 8 TB/s = 19.7 FLOP/B - HBM-bound, e.g. the 1x1 channel expansions of the key encoder.
- * They are part of the STCN_K_CONV totals; out[4] = { FLOP, bytes, device ms (profiling on), launches }. */
-int stcn_get_conv_regimes(stcn_engine *e, double *out /*[4]*/);
+ * They are part of the STCN_K_CONV totals; out[6] = { FLOP, bytes, device ms (profiling on), launches of those launches,
+ * algorithmic FLOP of the convs that ran as Winograd F(2x2,3x3), ... as Winograd F(4x4,3x3) }. */
+int stcn_get_conv_regimes(stcn_engine *e, double *out /*[6]*/);
 
 /* ---- caller-side metric -------------------------------------------------------
  * Integer counts behind J (region IoU) and F (boundary measure) for T frames, on the device.
