@@ -18,6 +18,13 @@ def test_lpt_is_balanced_and_deterministic():
     loads = [sum(costs[i] for i in r) for r in a]
     assert max(loads) - min(loads) <= max(costs) // 2
     assert shard.lpt_assign(costs, 1) == [sorted(range(len(costs)), key=lambda i: (-costs[i], i))]
+    # the 30 DAVIS-2017-val sequence lengths (what bench.py --workload davis-val shards): within 1 % of the mean on 2, 4, 8 ranks
+    davis = [69, 50, 80, 84, 90, 75, 40, 104, 90, 60, 66, 52, 50, 90, 78, 50, 81, 34, 50, 47, 49, 50, 79, 40, 80, 100, 79, 43, 40, 99]
+    for world in (2, 4, 8):
+        parts = shard.lpt_assign([t - 1 for t in davis], world)
+        assert sorted(i for r in parts for i in r) == list(range(30))
+        loads = [sum(davis[i] - 1 for i in r) for r in parts]
+        assert max(loads) <= 1.01 * sum(loads) / world, (world, loads)
 
 
 def _worker(rank, world, port, q):
