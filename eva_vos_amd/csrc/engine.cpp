@@ -274,7 +274,10 @@ int Work::init(int nh, int nw, int k_, int key_batch, int group) {
         if ((rc = alloc((void **)b, S * sizeof(float)))) return rc;
     splitk_floats = (size_t)32 * 1024 * 1024;      // 128 MB of fp32 slabs; conv falls back to fewer splits
     if ((rc = alloc((void **)&splitk, splitk_floats * sizeof(float)))) return rc;
-    {   // Winograd V of the largest 3x3 conv this workspace serves: 256 channels at 1/4 scale over the largest batch
+    {   // Winograd V of the largest 3x3 conv this workspace serves: 256 channels at 1/4 scale over the largest batch.  Both kinds
+        // of workspace reach that shape: the decoder's (objects x frames of a decode group) with up_8_4, and the key encoder's
+        // (key_batch frames; also the side-stream workspace) with decoder.up_8_4.skip_conv, which encode_key runs per frame -
+        // so neither can be sized from the trunk's 128-channel convs alone.  F(2x2) needs 4x the conv input, F(4x4) 2.25x.
         static const bool wino = [] { const char *e = getenv("STCN_WINOGRAD"); return !e || atoi(e) != 0; }();
         int maxb = key_batch > k * group ? key_batch : k * group;
         const long mt = ((long)maxb * ((d.h4 + 1) / 2) * ((d.w4 + 1) / 2) + 63) / 64 * 64;
