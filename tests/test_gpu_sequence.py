@@ -544,3 +544,37 @@ def test_weight_snapshots_are_kept_per_fusion_net_and_data_writes_are_seen(weigh
             if t.is_floating_point():
                 t.data.mul_(1.0009765625)                       # exact in fp32, invisible to _version
     assert IC._model_for(p, f1, 0) is not m1, "a .data update of every tensor must yield a fresh snapshot"
+
+
+def test_480p_multi_object_decode_groups_match_the_oracle(nets, weights):
+    """The k > 1 decode-group path (objects x frames in one batch, per-frame tensors broadcast by a modulo batch index) at the
+    BASELINE resolution against the CPU oracle: 480x854, 3 objects, mem_freq = 3 (groups of 3 frames), two rounds with fusion.
+    Statements as for the `seq480k5` fixture: per-object mask IoU on the pixels whose label is well-conditioned in the ORACLE's
+    own probabilities (top-1 minus top-2 >= 1e-2; elsewhere the argmax hangs on fp32 rounding, section 2 of DESIGN.md), on the
+    clip and on every frame; probabilities everywhere, tail against 3 x the reference's own tail at 480p with several objects."""
+    T, H, W, k = 8, 480, 854, 3
+    img, msk = synth.synthetic_clip(T, H, W, seed=41), synth.synthetic_mask(T, H, W, k, seed=42)
+    core = make_core(nets)(img, k, 3)
+    orc = O.OracleCore(weights[0], weights[1], img, k, mem_freq=3)
+    noise = load_golden("selfnoise")["seq480k5"][0]
+    for idx in (0, 5):
+        m = torch.cat([1 - msk[:, idx].sum(0, keepdim=True).clamp(0, 1), msk[:, idx]], 0)
+        a, b = core.interact(m, idx, scribble=True), orc.interact(m.clone(), idx, scribble=True)
+        lw, uw, lh, uh = orc.pad
+        po = orc.prob[:, :, 0, lh:orc.prob.shape[3] - uh if uh else None, lw:orc.prob.shape[4] - uw if uw else None]
+        top = torch.topk(po, 2, dim=0).values
+        dec = ((top[0] - top[1]) >= 1e-2).numpy()
+        assert dec.mean() > 0.1, "hardly any decisive pixel: the comparison would be vacuous"
+        for o in range(1, k + 1):
+            ma, mb = (a == o) & dec, (b == o) & dec
+            assert iou(ma, mb) >= 1 - 1e-3, (idx, o, iou(ma, mb))
+            miss, fr = frame_miss(ma, mb)
+            px = (ma[fr] | mb[fr]).sum() if fr >= 0 else 1
+            assert miss <= frame_bound(0.0, px), (idx, o, fr, miss)
+        d = (core.prob.cpu() - orc.prob).abs().numpy()
+        q999 = float(np.quantile(d.reshape(-1)[::5], 0.999))
+        print(f"480p k=3 groups, interact({idx}): {100 * dec.mean():.1f} % decisive pixels, {int((a != b).sum())} mask pixels differ in all, "
+              f"{int(((a != b) & dec).sum())} on decisive pixels; |dprob| p99.9 {q999:.1e} max {d.max():.1e}")
+        assert q999 <= 3 * float(noise[2]) + 5e-4, (idx, q999)
+    s_ = core.stats()
+    assert s_["fused"] > 0 and s_["frames"] == T - 2
