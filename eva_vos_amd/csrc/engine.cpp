@@ -290,7 +290,7 @@ int Work::init(int nh, int nw, int k_, int key_batch, int group) {
     if ((rc = alloc((void **)&logit4, (size_t)kg * d.hw4 * sizeof(float)))) return rc;
     if ((rc = alloc((void **)&flogit, (size_t)k * d.npix * sizeof(float)))) return rc;
     if ((rc = alloc((void **)&agg, (size_t)(k + 1) * group * d.npix * sizeof(float)))) return rc;
-    if ((rc = alloc((void **)&pooled, (size_t)(k + 1) * 2 * d.hw16 * sizeof(float)))) return rc;
+    if ((rc = alloc((void **)&pooled, (size_t)20 * d.hw16 * sizeof(float)))) return rc;        // [hw16][channels padded to 4 / 8 / 12 / 20]
     if ((rc = alloc((void **)&amap, (size_t)(k + 1) * 2 * d.hw16 * sizeof(float)))) return rc;
     if ((rc = alloc((void **)&attn, (size_t)(k + 1) * 2 * d.npix * sizeof(float)))) return rc;
     // memory-read scratch for Q = group * hw16 queries (a decode group is read in one pass)

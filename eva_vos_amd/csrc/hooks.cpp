@@ -250,7 +250,7 @@ int stcn_test_attention(void *stream, const float *mk, const float *qk, const fl
     const int h = nh / 16, w = nw / 16;
     DevBuf msq, pooled, amap, gm, cm, part;
     RC(gm.alloc((size_t)256 * h * w)); RC(cm.alloc(h * w)); RC(part.alloc((size_t)16 * h * w * 19));
-    RC(msq.alloc(h * w + 64)); RC(pooled.alloc((size_t)kk * 2 * h * w)); RC(amap.alloc((size_t)kk * 2 * h * w));
+    RC(msq.alloc(h * w + 64)); RC(pooled.alloc((size_t)20 * h * w)); RC(amap.alloc((size_t)kk * 2 * h * w));
     rowsumsq_launch(mk, h * w, 64, msq.p, s);
     HIPCHK(hipMemsetAsync(msq.p, 0, (size_t)(h * w + 64) * 4, s));
     rowsumsq_launch(mk, h * w, 64, msq.p, s);

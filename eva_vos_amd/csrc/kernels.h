@@ -146,7 +146,7 @@ void allow_big_lds(const void *kernel, size_t lds);
 void memory_read_launch(const float *mk, const float *msq, const float *qk, int N, int Q,
                         const float *mv, long mv_os, int k, float *readout, long ro_os,
                         int32_t *topk_idx, float *topk_w, MemReadScratch scr, hipStream_t s);
-// fusion attention read: mk,qk [hw,64]; pos,neg [kk][16h*16w planes] -> attn [kk][2][nh*nw]
+// fusion attention read: mk,qk [hw,64]; pos,neg [kk][16h*16w planes] -> attn [kk][2][nh*nw]; pooled: scratch of 20 * h * w floats
 struct AttnScratch { float *gmax, *cmax, *part; };   // [256][hw], [hw], [16][hw][19]
 // pos == nullptr: `pooled` already holds attention_pool_launch's output for this interaction
 void attention_pool_launch(const float *pos, const float *neg, int kk, int h, int w, float *pooled, hipStream_t s);

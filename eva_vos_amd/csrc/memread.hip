@@ -607,31 +607,37 @@ void merge_only_launch(const float *cand_v, const int32_t *cand_i, int NC, int Q
 // ------------------------------------------------------------------------------------------------
 // Fusion attention read (prop_net.py:117-138,198-211): W = softmax over memory rows of the T=1
 // affinity; amap[kk][ch][q] = sum_m pooled[kk][ch][m] W[m][q]; then bilinear x16.
+// pooled_t [h*w cells][nchp]: channel c = 2 * row + (0: pos, 1: neg) of the kk mask rows, 16x16 block means (F.interpolate
+// mode='area'), zero for c >= 2 kk; cell-major so that the pass kernel fetches a memory row's channels as contiguous 16-byte loads
 __global__ void area_pool16_kernel(const float *__restrict__ pos, const float *__restrict__ neg, int kk, int h,
-                                   int w, float *__restrict__ pooled) {
-    // pooled [kk][2][h*w]; one thread per output cell, 16x16 block mean (F.interpolate mode='area')
+                                   int w, int nchp, float *__restrict__ pooled) {
     const long i = blockIdx.x * 256L + threadIdx.x;
     const int hw = h * w;
-    if (i >= (long)kk * 2 * hw) return;
+    if (i >= (long)nchp * hw) return;
     const int cell = (int)(i % hw);
-    const int ch = (int)((i / hw) % 2);
-    const int r = (int)(i / (2L * hw));
-    const int cy = cell / w, cx = cell - cy * w;
-    const int W = 16 * w;
-    const float *src = (ch == 0 ? pos : neg) + (long)r * 256 * hw + (long)cy * 16 * W + cx * 16;
+    const int c = (int)(i / hw);
     float acc = 0.f;
-    for (int y = 0; y < 16; ++y) {
-        const f32x4 *p = reinterpret_cast<const f32x4 *>(src + (long)y * W);
-        const f32x4 a = p[0], b = p[1], c = p[2], d = p[3];
-        acc += (a.x + a.y + a.z + a.w) + (b.x + b.y + b.z + b.w) + (c.x + c.y + c.z + c.w) + (d.x + d.y + d.z + d.w);
+    if (c < 2 * kk) {
+        const int ch = c & 1, r = c >> 1;
+        const int cy = cell / w, cx = cell - cy * w;
+        const int W = 16 * w;
+        const float *src = (ch == 0 ? pos : neg) + (long)r * 256 * hw + (long)cy * 16 * W + cx * 16;
+        for (int y = 0; y < 16; ++y) {
+            const f32x4 *p = reinterpret_cast<const f32x4 *>(src + (long)y * W);
+            const f32x4 a = p[0], b = p[1], cc = p[2], d = p[3];
+            acc += (a.x + a.y + a.z + a.w) + (b.x + b.y + b.z + b.w) + (cc.x + cc.y + cc.z + cc.w) + (d.x + d.y + d.z + d.w);
+        }
     }
-    pooled[i] = acc * (1.f / 256.f);
+    pooled[(long)cell * nchp + c] = acc * (1.f / 256.f);
 }
+
+// channels of the attention read padded to the instantiated widths (2 (k + 1) = 4 ... 18)
+static int attention_nchp(int nch) { return nch <= 4 ? 4 : (nch <= 8 ? 8 : (nch <= 12 ? 12 : 20)); }
 
 #define STCN_ATT_MAXCH 18   // (k+1)*2 with k <= 8
 // pass 2 of the attention read: per (query block, row chunk) partial sums of e = exp(S - cmax[q]), cmax = exact column maximum:
 //   part[chunk][q][0] = sum_m e,  part[chunk][q][1 + c] = sum_m e * pooled[c][m]
-template <int WAVES>
+template <int WAVES, int NCHP>
 __global__ __launch_bounds__(64 * WAVES) void attention_pass_kernel(
     const float *__restrict__ mk, const float *__restrict__ msq, const float *__restrict__ qk, int N, int Q,
     int steps_per_chunk, const float *__restrict__ gmax, int G, const float *__restrict__ pooled, int nch,
@@ -654,46 +660,51 @@ __global__ __launch_bounds__(64 * WAVES) void attention_pass_kernel(
     for (int gi = g; gi < G; gi += 4) cm = fmaxf(cm, gmax[(long)gi * Q + qcol]);
     cm = fmaxf(cm, __shfl_xor(cm, 16));
     cm = fmaxf(cm, __shfl_xor(cm, 32));
-    float l = 0.f, a[STCN_ATT_MAXCH];
+    float l = 0.f, a[NCHP];
 #pragma unroll
-    for (int c = 0; c < STCN_ATT_MAXCH; ++c) a[c] = 0.f;
+    for (int c = 0; c < NCHP; ++c) a[c] = 0.f;
     for (int h = h0; h < h1; ++h) {
         const int row0 = h * HROWS;
         HalfFrag hf;
         load_half(mk, msq, N, row0, lane, hf);
+        // the pooled channels of this lane's memory rows: NCHP / 4 16-byte loads per row; the 4 rows of row block 0 are requested
+        // before the MFMAs of the step, those of block rb + 1 before the arithmetic of block rb (round 2: scalar loads behind
+        // `if (c < nch)` - the compiler waited for each of the up to 72 per row block)
+        f32x4 pl[2][4][NCHP / 4];
+        auto pload = [&](int rb, f32x4 (&d)[4][NCHP / 4]) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int rr = min(row0 + rb * 16 + 4 * g + j, N - 1);
+#pragma unroll
+                for (int c4 = 0; c4 < NCHP / 4; ++c4) d[j][c4] = *reinterpret_cast<const f32x4 *>(pooled + (long)rr * NCHP + 4 * c4);
+            }
+        };
+        pload(0, pl[0]);
         f32x4 acc[4];
         mfma_half(hf, bq, acc);
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) {
+            if (rb < 3) pload(rb + 1, pl[(rb + 1) & 1]);
             const int r = row0 + rb * 16 + 4 * g;
-            f32x4 e;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                e[j] = r + j < N ? expf(acc[rb][j] - cm) : 0.f;
-                l += e[j];
+                const float e = r + j < N ? expf(acc[rb][j] - cm) : 0.f;
+                l += e;
+#pragma unroll
+                for (int c = 0; c < NCHP; ++c) a[c] += e * pl[rb & 1][j][c >> 2][c & 3];
             }
-#pragma unroll
-            for (int c = 0; c < STCN_ATT_MAXCH; ++c)
-                if (c < nch) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int rr = r + j < N ? r + j : N - 1;
-                        a[c] += e[j] * pooled[(long)c * N + rr];
-                    }
-                }
         }
     }
     // sum the 4 lane groups that share a query column (fixed order -> deterministic)
     l += __shfl_xor(l, 16);
     l += __shfl_xor(l, 32);
 #pragma unroll
-    for (int c = 0; c < STCN_ATT_MAXCH; ++c)
-        if (c < nch) { a[c] += __shfl_xor(a[c], 16); a[c] += __shfl_xor(a[c], 32); }
+    for (int c = 0; c < NCHP; ++c) { a[c] += __shfl_xor(a[c], 16); a[c] += __shfl_xor(a[c], 32); }
     if (g == 0 && q0 + col < Q) {
         float *dst = part + ((long)chunk * Q + q0 + col) * (1 + STCN_ATT_MAXCH);
         dst[0] = l;
 #pragma unroll
-        for (int c = 0; c < STCN_ATT_MAXCH; ++c)
+        for (int c = 0; c < NCHP; ++c)
             if (c < nch) dst[1 + c] = a[c];
     }
 }
@@ -731,10 +742,11 @@ __global__ void bilinear_up16_kernel(const float *__restrict__ amap, int nch, in
              fy * ((1.f - fx) * a[y1 * w + x0] + fx * a[y1 * w + x1]);
 }
 
-// pooled [kk][2][h*w] = 16x16 block means of the +/- mask differences of the current interaction: the same for every frame
+// pooled_t [h*w][nchp] = 16x16 block means of the +/- mask differences of the current interaction: the same for every frame
 // of the round, so the engine computes it once per interaction (pos == nullptr below)
 void attention_pool_launch(const float *pos, const float *neg, int kk, int h, int w, float *pooled, hipStream_t s) {
-    hipLaunchKernelGGL(area_pool16_kernel, dim3((unsigned)(((long)kk * 2 * h * w + 255) / 256)), dim3(256), 0, s, pos, neg, kk, h, w, pooled);
+    const int nchp = attention_nchp(2 * kk);
+    hipLaunchKernelGGL(area_pool16_kernel, dim3((unsigned)(((long)nchp * h * w + 255) / 256)), dim3(256), 0, s, pos, neg, kk, h, w, nchp, pooled);
 }
 
 void attention_read_launch(const float *mk, const float *msq, const float *qk, const float *pos, const float *neg,
@@ -752,8 +764,14 @@ void attention_read_launch(const float *mk, const float *msq, const float *qk, c
     const int NCeff = (steps + spc - 1) / spc;
     const dim3 grid(qblocks, NCeff);
     hipLaunchKernelGGL((colmax_pass_kernel<WAVES>), grid, dim3(64 * WAVES), 0, s, mk, msq, qk, hw, hw, spc, scr.gmax);
-    hipLaunchKernelGGL((attention_pass_kernel<WAVES>), grid, dim3(64 * WAVES), 0, s, mk, msq, qk, hw, hw, spc, scr.gmax, NCeff * NGRP,
-                       pooled, nch, scr.part);
+    switch (attention_nchp(nch)) {
+#define STCN_AP(N_) hipLaunchKernelGGL((attention_pass_kernel<WAVES, N_>), grid, dim3(64 * WAVES), 0, s, mk, msq, qk, hw, hw, spc, scr.gmax, NCeff * NGRP, pooled, nch, scr.part)
+        case 4: STCN_AP(4); break;
+        case 8: STCN_AP(8); break;
+        case 12: STCN_AP(12); break;
+        default: STCN_AP(20); break;
+#undef STCN_AP
+    }
     hipLaunchKernelGGL(attention_finalize_kernel, dim3((hw + 255) / 256), dim3(256), 0, s, scr.part, NCeff, hw, nch,
                        amap);
     const long tot = (long)nch * 256 * hw;
