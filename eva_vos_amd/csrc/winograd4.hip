@@ -130,7 +130,7 @@ struct Wino4G {
 // fewer L2 bytes per MFMA, half the U traffic): 96 accumulator registers leave room for two HALF fragment sets - the loop walks
 // half-steps (k-block, 32-tile block) and loads one half-step ahead (12 MFMAs x 3 waves sharing the SIMD: ~2300 cycles).
 template <int MB>
-__global__ __launch_bounds__(64 * W4W) void wino4_gemm_kernel(const Wino4G p, const int tiles_n, const int dbg) {
+__global__ __launch_bounds__(64 * W4W) void wino4_gemm_kernel(const Wino4G p, const int tiles_n) {
     constexpr int PPW = 3, WT = W4T * MB;
     extern __shared__ __attribute__((aligned(16))) float smem[];          // epilogue: [36][32 tiles][32 channels]
     const int nblk = gridDim.x;
@@ -151,8 +151,7 @@ __global__ __launch_bounds__(64 * W4W) void wino4_gemm_kernel(const Wino4G p, co
         sa0[pi] = (unsigned)((((long)(pos0 + pi) * p.KB) * p.Mt_pad + tm * WT) * 32);
         sb0[pi] = (unsigned)((((long)(pos0 + pi) * p.KB) * p.N + tn * W4N) * 32);
     }
-    unsigned sa = (unsigned)p.Mt_pad * 32u, sb = (unsigned)p.N * 32u;   // bytes per k-block
-    if (dbg & 2) { sa = 0; sb = 0; for (int pi = 0; pi < PPW; ++pi) { sa0[pi] = 0; sb0[pi] = 0; } }
+    const unsigned sa = (unsigned)p.Mt_pad * 32u, sb = (unsigned)p.N * 32u;   // bytes per k-block
 
     f32x16 acc[PPW][MB];
 #pragma unroll
@@ -255,13 +254,6 @@ __global__ __launch_bounds__(64 * W4W) void wino4_gemm_kernel(const Wino4G p, co
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    if (dbg & 1) {            // timing experiment: main loop only
-        float sum = 0.f;
-        for (int pi = 0; pi < PPW; ++pi) for (int bi = 0; bi < MB; ++bi) for (int e = 0; e < 16; ++e) sum += acc[pi][bi][e];
-        if (sum == 12345.f) p.y[t] = sum;
-        return;
-    }
-
     // ---- epilogue, 32 tiles at a time: all 36 positions of 32 x 32 (tile, channel) pairs meet in LDS, Y = A^T M A
     const int n_l = t & 31, tsub = t >> 5;                                    // thread -> (channel, tiles tsub, tsub + 24)
     const int tpi = p.TH * p.TW, ohw = p.OH * p.OW;
@@ -386,21 +378,19 @@ void wino4_launch(const ConvP &p, float *V, hipStream_t s, hipEvent_t *ev_in, hi
     const int mb = mb_env == 1 || mb_env == 2 ? mb_env : ((Mt_pad / (2 * W4T)) * tiles_n >= 200 ? 2 : 1);
     const int tiles_m = Mt_pad / (W4T * mb);
     g.fd_tpi = fastdiv_make((unsigned)(TH * TW)); g.fd_tw = fastdiv_make((unsigned)TW); g.fd_tiles_n = fastdiv_make((unsigned)tiles_n);
-    const char *dbg_s = getenv("STCN_W4_DBG");
-    const int dbg = dbg_s ? atoi(dbg_s) : 0;
     const size_t lds = (size_t)36 * W4T * W4N * sizeof(float);
     if (mb == 2) {
         allow_big_lds(reinterpret_cast<const void *>(&wino4_gemm_kernel<2>), lds);
         if (ev_gemm)
-            hipExtLaunchKernelGGL(wino4_gemm_kernel<2>, dim3(tiles_m * tiles_n), dim3(64 * W4W), lds, s, ev_gemm[0], ev_gemm[1], 0, g, tiles_n, dbg);
+            hipExtLaunchKernelGGL(wino4_gemm_kernel<2>, dim3(tiles_m * tiles_n), dim3(64 * W4W), lds, s, ev_gemm[0], ev_gemm[1], 0, g, tiles_n);
         else
-            hipLaunchKernelGGL(wino4_gemm_kernel<2>, dim3(tiles_m * tiles_n), dim3(64 * W4W), lds, s, g, tiles_n, dbg);
+            hipLaunchKernelGGL(wino4_gemm_kernel<2>, dim3(tiles_m * tiles_n), dim3(64 * W4W), lds, s, g, tiles_n);
     } else {
         allow_big_lds(reinterpret_cast<const void *>(&wino4_gemm_kernel<1>), lds);
         if (ev_gemm)
-            hipExtLaunchKernelGGL(wino4_gemm_kernel<1>, dim3(tiles_m * tiles_n), dim3(64 * W4W), lds, s, ev_gemm[0], ev_gemm[1], 0, g, tiles_n, dbg);
+            hipExtLaunchKernelGGL(wino4_gemm_kernel<1>, dim3(tiles_m * tiles_n), dim3(64 * W4W), lds, s, ev_gemm[0], ev_gemm[1], 0, g, tiles_n);
         else
-            hipLaunchKernelGGL(wino4_gemm_kernel<1>, dim3(tiles_m * tiles_n), dim3(64 * W4W), lds, s, g, tiles_n, dbg);
+            hipLaunchKernelGGL(wino4_gemm_kernel<1>, dim3(tiles_m * tiles_n), dim3(64 * W4W), lds, s, g, tiles_n);
     }
 }
 
