@@ -112,9 +112,12 @@ int make_wino4(Model &m, ConvW &cw, const std::vector<float> &w) {
     return upload(m, u, &cw.wino4_u);
 }
 
-// F(4x4,3x3) is reserved for the decoder side (its outputs become probabilities and memory values, never the keys that decide
-// top-50 membership): the decoder proper and its frame-only skip convs
-static bool decoder_layer(const std::string &name) { return name.compare(0, 8, "decoder.") == 0; }
+// F(4x4,3x3) is reserved for layers whose outputs become probabilities or memory VALUES, never the keys that decide top-50
+// membership: the decoder proper with its frame-only skip / compress convs, key_comp (f16_thin only feeds the decoder) and the
+// value encoder's fuser.  The ResNet trunks and key_proj stay on F(2x2) / direct kernels
+static bool decoder_layer(const std::string &name) {
+    return name.compare(0, 8, "decoder.") == 0 || name == "key_comp" || name.compare(0, 20, "value_encoder.fuser.") == 0;
+}
 
 static int add_convs(Model &m, const std::map<std::string, HostT> &sd) {
     for (auto &kv : sd) {
@@ -390,6 +393,7 @@ int run_conv(const Model &m, Work &w, hipStream_t s, const char *name, const flo
         eg = w.prof->attach(cls, hbm_acc);
         if (wino4) {
             ei = w.prof->attach(STCN_K_WINO_INPUT);
+            if (wino4_tail_split(p, w.splitk_floats)) er = w.prof->attach(STCN_K_CONV_REDUCE);
         } else if (wino) {
             ei = w.prof->attach(STCN_K_WINO_INPUT);
             if (wino_plan_splitk(p, w.splitk_floats) > 1) er = w.prof->attach(STCN_K_CONV_REDUCE);
@@ -398,7 +402,7 @@ int run_conv(const Model &m, Work &w, hipStream_t s, const char *name, const flo
         }
     }
     if (fus) fusion_conv_launch(p, s, eg);
-    else if (wino4) wino4_launch(p, w.wino_v, s, ei, eg);
+    else if (wino4) wino4_launch(p, w.wino_v, w.splitk_floats, s, ei, eg, er);
     else if (wino) wino_launch(p, w.wino_v, w.splitk_floats, s, ei, eg, er);
     else conv_launch(p, s, eg, er);
     return launch_status(name);

@@ -43,7 +43,7 @@ struct Model {
     std::map<std::string, ConvW> conv;
     CbamW cbam{};
     bool has_fuse = false;
-    int wino4_min_wg = 384;                // fewest workgroups for which a flagged layer takes the F(4x4) kernel (tests: 0)
+    int wino4_min_wg = 100;                // fewest 32 x 32 workgroups for which a flagged layer takes the F(4x4) kernel (tests: 0)
     std::vector<void *> allocs;
     const ConvW &c(const std::string &name) const;
 };

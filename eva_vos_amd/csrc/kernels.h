@@ -80,7 +80,10 @@ int wino_plan_splitk(const ConvP &p, size_t slab_floats);
 void wino_transform_weights(const float *w, int N, int Cin, int Kp, float *U);
 // Winograd F(4x4,3x3) path (winograd4.hip, decoder layers): V workspace floats, or 0 when not eligible / fewer than min_wg workgroups
 size_t wino4_workspace_floats(const ConvP &p, int min_wg);
-void wino4_launch(const ConvP &p, float *V, hipStream_t s, hipEvent_t *ev_in = nullptr, hipEvent_t *ev_gemm = nullptr);
+void wino4_launch(const ConvP &p, float *V, size_t slab_floats, hipStream_t s, hipEvent_t *ev_in = nullptr, hipEvent_t *ev_gemm = nullptr,
+                  hipEvent_t *ev_red = nullptr);
+// does wino4_launch cut the last round of this conv's workgroups into K pieces (a reduce launch follows)?
+bool wino4_tail_split(const ConvP &p, size_t slab_floats);
 void wino4_transform_weights(const float *w, int N, int Cin, int Kp, float *U);
 
 // FusionNet convs (fusion_conv.hip): 3x3, stride 1, Cout = 32, Cin = 32 or 12, one dense image: weights in registers, patch in LDS

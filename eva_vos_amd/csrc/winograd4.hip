@@ -124,6 +124,11 @@ struct Wino4G {
     float *y; long y_bs;
     int relu_out;
     FastDiv fd_tpi, fd_tw, fd_tiles_n;
+    // tail split (MB = 1 only): workgroups [0, full_wg) compute whole tiles; the remaining tiles are cut into `pieces` ranges of
+    // kb_per_piece k-blocks whose output-domain partial sums (the output transform is linear) go to `partial`
+    // [(tile - full_wg) * pieces + piece][32 tiles][16 pixels][32 channels] and are summed by wino4_reduce_kernel
+    int full_wg, pieces, kb_per_piece;
+    float *partial;
 };
 
 // MB = 32-tile blocks per workgroup.  MB = 1: three fragment sets, loads two k-blocks ahead.  MB = 2 (64 tiles x 32 channels: 25 %
@@ -133,9 +138,21 @@ template <int MB>
 __global__ __launch_bounds__(64 * W4W) void wino4_gemm_kernel(const Wino4G p, const int tiles_n) {
     constexpr int PPW = 3, WT = W4T * MB;
     extern __shared__ __attribute__((aligned(16))) float smem[];          // epilogue: [36][32 tiles][32 channels]
-    const int nblk = gridDim.x;
-    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = blockIdx.x & 7;
-    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+    auto xcd_contiguous = [](int bid, int nb) {
+        const int q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7;
+        return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    };
+    int swz, piece = -1, kb0 = 0, kb1 = p.KB;
+    if (MB == 1 && p.pieces > 1 && (int)blockIdx.x >= p.full_wg) {           // a K piece of one of the last tiles
+        const int j = xcd_contiguous((int)blockIdx.x - p.full_wg, (int)gridDim.x - p.full_wg);
+        const int rt = j / p.pieces;
+        piece = j - rt * p.pieces;
+        swz = p.full_wg + rt;
+        kb0 = piece * p.kb_per_piece;
+        kb1 = min(p.KB, kb0 + p.kb_per_piece);
+    } else {
+        swz = xcd_contiguous(blockIdx.x, MB == 1 && p.pieces > 1 ? p.full_wg : (int)gridDim.x);
+    }
     const int tm = fastdiv(swz, p.fd_tiles_n), tn = swz - tm * tiles_n;
     const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);                  // wave-uniform: the position offsets below stay in SGPRs
@@ -148,8 +165,8 @@ __global__ __launch_bounds__(64 * W4W) void wino4_gemm_kernel(const Wino4G p, co
     unsigned sa0[PPW], sb0[PPW];
 #pragma unroll
     for (int pi = 0; pi < PPW; ++pi) {
-        sa0[pi] = (unsigned)((((long)(pos0 + pi) * p.KB) * p.Mt_pad + tm * WT) * 32);
-        sb0[pi] = (unsigned)((((long)(pos0 + pi) * p.KB) * p.N + tn * W4N) * 32);
+        sa0[pi] = (unsigned)((((long)(pos0 + pi) * p.KB + kb0) * p.Mt_pad + tm * WT) * 32);
+        sb0[pi] = (unsigned)((((long)(pos0 + pi) * p.KB + kb0) * p.N + tn * W4N) * 32);
     }
     const unsigned sa = (unsigned)p.Mt_pad * 32u, sb = (unsigned)p.N * 32u;   // bytes per k-block
 
@@ -161,7 +178,7 @@ __global__ __launch_bounds__(64 * W4W) void wino4_gemm_kernel(const Wino4G p, co
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[pi][bi][e] = 0.f;
 
-    const int nk = p.KB;
+    const int nk = kb1 - kb0;
     auto load1 = [&](int k, int pi, f32x4 (&fa)[MB], f32x4 &fb) {
         const unsigned oa = sa0[pi] + (unsigned)k * sa, ob = sb0[pi] + (unsigned)k * sb;
 #pragma unroll
@@ -290,6 +307,19 @@ __global__ __launch_bounds__(64 * W4W) void wino4_gemm_kernel(const Wino4G p, co
                 z[xi][2] = s12 * 0.5625f + s34 * 2.25f;
                 z[xi][3] = d12 * 0.421875f + d34 * 3.375f + m[5];            // 27/64, 27/8
             }
+            if (MB == 1 && piece >= 0) {
+                // K piece: the 16 outputs of (tile, channel) of THIS k range, no bias / residual / ReLU, into the tile-local slab
+                float *dst = p.partial + (((long)(swz - p.full_wg) * p.pieces + piece) * W4T + tl) * (16 * W4N) + n_l;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float s12 = z[1][j] + z[2][j], d12 = z[1][j] - z[2][j], s34 = z[3][j] + z[4][j], d34 = z[3][j] - z[4][j];
+                    dst[(0 * 4 + j) * W4N] = z[0][j] + s12 + s34;
+                    dst[(1 * 4 + j) * W4N] = d12 * 0.75f + d34 * 1.5f;
+                    dst[(2 * 4 + j) * W4N] = s12 * 0.5625f + s34 * 2.25f;
+                    dst[(3 * 4 + j) * W4N] = d12 * 0.421875f + d34 * 3.375f + z[5][j];
+                }
+                continue;
+            }
             const float *resb = p.res ? p.res + (long)(p.res_bmod ? b % p.res_bmod : b) * p.res_bs + n : nullptr;
             float *yb = p.y + (p.y_bs ? (long)b * p.y_bs : (long)b * ohw * p.N) + n;
             // the 16 residual values of the tile are requested TOGETHER, before the column transform (a load behind `if (resb)`
@@ -331,6 +361,36 @@ __global__ __launch_bounds__(64 * W4W) void wino4_gemm_kernel(const Wino4G p, co
     }
 }
 
+// tail split: y(tile) = sum over the K pieces of the tile-local partial outputs + bias / residual / ReLU.  One thread per output
+// value: 64 workgroups per split tile (32 tiles x 16 pixels x 32 channels), the up to 8 partial values requested together.
+__global__ __launch_bounds__(256) void wino4_reduce_kernel(const Wino4G p, const int tiles_n) {
+    const int rt = blockIdx.x >> 6, swz = p.full_wg + rt;
+    const int tm = fastdiv(swz, p.fd_tiles_n), tn = swz - tm * tiles_n;
+    const int n_l = threadIdx.x & 31;
+    const int e = ((blockIdx.x & 63) << 3) + (threadIdx.x >> 5);              // tile-local tile * 16 + pixel
+    const int tl = e >> 4, px = e & 15;
+    const int n = tn * W4N + n_l;
+    const long gt = (long)tm * W4T + tl;
+    if (gt >= p.Mt) return;
+    const int tpi = p.TH * p.TW, ohw = p.OH * p.OW;
+    const int b = fastdiv((int)gt, p.fd_tpi);
+    const int rr = (int)(gt - (long)b * tpi);
+    const int ty = fastdiv(rr, p.fd_tw), tx = rr - ty * p.TW;
+    const int oh = 4 * ty + (px >> 2), ow = 4 * tx + (px & 3);
+    if (oh >= p.OH || ow >= p.OW) return;
+    const float *src = p.partial + ((long)rt * p.pieces * W4T * 16 + e) * W4N + n_l;
+    float pv[8];
+#pragma unroll
+    for (int s2 = 0; s2 < 8; ++s2) pv[s2] = src[(long)min(s2, p.pieces - 1) * (W4T * 16 * W4N)];      // pieces <= 8; extra reads repeat the last
+    const long po = ((long)oh * p.OW + ow) * p.N + n;
+    const float rv = p.res ? p.res[(long)(p.res_bmod ? b % p.res_bmod : b) * p.res_bs + po] : 0.f;
+    float v = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < 8; ++s2) v += s2 < p.pieces ? pv[s2] : 0.f;
+    v += (p.bias ? p.bias[n] : 0.f) + rv;
+    p.y[(p.y_bs ? (long)b * p.y_bs : (long)b * ohw * p.N) + po] = fmaxf(v, p.relu_out ? 0.f : -__builtin_inff());
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 static int wino4_mode() {          // 0 off, 1 on for flagged layers with enough workgroups (default), 2 whenever the shape allows
     static const int m = [] { const char *e = getenv("STCN_WINO4"); return e ? atoi(e) : 1; }();
@@ -348,9 +408,48 @@ size_t wino4_workspace_floats(const ConvP &p, int min_wg) {
     return (size_t)36 * p.Cin * Mt_pad;
 }
 
-void wino4_launch(const ConvP &p, float *V, hipStream_t s, hipEvent_t *ev_in, hipEvent_t *ev_gemm) {
+// launch plan of the F(4x4) GEMM: 64- or 32-tile workgroups, and (32-tile only) the tail split
+struct W4Plan { int Mt, Mt_pad, tiles_m, tiles_n, mb, grid, full_wg, pieces, per; };
+static W4Plan wino4_plan(const ConvP &p, size_t slab_floats) {
+    static const int mb_env = [] { const char *e = getenv("STCN_WINO4_MB"); return e ? atoi(e) : 0; }();
+    static const bool tail_on = [] { const char *e = getenv("STCN_WINO4_TAIL"); return !e || atoi(e) != 0; }();
+    static const int cus = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+    W4Plan pl{};
+    const int TH = (p.OH + 3) / 4, TW = (p.OW + 3) / 4, KB = p.Cin / 8;
+    pl.Mt = p.B * TH * TW;
+    pl.Mt_pad = (pl.Mt + 2 * W4T - 1) / (2 * W4T) * (2 * W4T);
+    pl.tiles_n = p.N / W4N;
+    // 64-tile workgroups (25 % fewer L2 bytes per MFMA: +6 % at 1/4 and 1/8 scale) unless they would leave CUs idle
+    pl.mb = mb_env == 1 || mb_env == 2 ? mb_env : ((pl.Mt_pad / (2 * W4T)) * pl.tiles_n >= 200 ? 2 : 1);
+    pl.tiles_m = pl.Mt_pad / (W4T * pl.mb);
+    pl.grid = pl.tiles_m * pl.tiles_n;
+    pl.full_wg = pl.grid; pl.pieces = 1; pl.per = KB;
+    // Tail split (32-tile workgroups): one workgroup per CU is resident (144 KB of LDS), so a grid of 288 workgroups - the
+    // 1/16-scale 512-channel layers over a 5-frame group - costs two rounds for 1.125 rounds of work.  The whole rounds run as they
+    // are; the tiles of the ragged last round are cut into K pieces that fill the chip once more (32 tiles x 8 pieces of 8 k-blocks:
+    // 1.125 instead of 2 tile times) and meet in wino4_reduce_kernel.
+    if (tail_on && pl.mb == 1 && p.partial) {
+        const int full = pl.grid / cus * cus, rem = pl.grid - full;
+        if (full >= cus && rem > 0 && rem <= cus / 2) {
+            int sp = cus / rem;
+            sp = sp > 8 ? 8 : sp;
+            while (sp > 1 && KB / sp < 8) --sp;                               // at least 8 k-blocks per piece
+            const int per = (KB + sp - 1) / sp;
+            sp = (KB + per - 1) / per;
+            if (sp > 1 && (size_t)rem * sp * W4T * 16 * W4N <= slab_floats) {
+                pl.full_wg = full; pl.pieces = sp; pl.per = per;
+                pl.grid = full + rem * sp;
+            }
+        }
+    }
+    return pl;
+}
+bool wino4_tail_split(const ConvP &p, size_t slab_floats) { return wino4_plan(p, slab_floats).pieces > 1; }
+
+void wino4_launch(const ConvP &p, float *V, size_t slab_floats, hipStream_t s, hipEvent_t *ev_in, hipEvent_t *ev_gemm, hipEvent_t *ev_red) {
+    const W4Plan pl = wino4_plan(p, slab_floats);
     const int TH = (p.OH + 3) / 4, TW = (p.OW + 3) / 4;
-    const int Mt = p.B * TH * TW, Mt_pad = (Mt + 2 * W4T - 1) / (2 * W4T) * (2 * W4T), KB = p.Cin / 8;
+    const int Mt = pl.Mt, Mt_pad = pl.Mt_pad, KB = p.Cin / 8;
     {
         const unsigned gx = (unsigned)((8L * Mt_pad + 255) / 256);
         const int NCB = p.Cin / 32;
@@ -373,11 +472,9 @@ void wino4_launch(const ConvP &p, float *V, hipStream_t s, hipEvent_t *ev_in, hi
     g.TH = TH; g.TW = TW; g.OH = p.OH; g.OW = p.OW; g.B = p.B; g.M = p.M;
     g.bias = p.bias; g.res = p.res; g.res_bs = p.res_bs; g.res_bmod = p.res_bmod; g.y = p.y; g.y_bs = p.y_bs; g.relu_out = p.relu_out;
     // 64-tile workgroups (25 % fewer L2 bytes per MFMA: +6 % at 1/4 and 1/8 scale) unless they would leave CUs idle
-    static const int mb_env = [] { const char *e = getenv("STCN_WINO4_MB"); return e ? atoi(e) : 0; }();
-    const int tiles_n = p.N / W4N;
-    const int mb = mb_env == 1 || mb_env == 2 ? mb_env : ((Mt_pad / (2 * W4T)) * tiles_n >= 200 ? 2 : 1);
-    const int tiles_m = Mt_pad / (W4T * mb);
+    const int tiles_n = pl.tiles_n, mb = pl.mb, tiles_m = pl.tiles_m, grid = pl.grid;
     g.fd_tpi = fastdiv_make((unsigned)(TH * TW)); g.fd_tw = fastdiv_make((unsigned)TW); g.fd_tiles_n = fastdiv_make((unsigned)tiles_n);
+    g.full_wg = pl.full_wg; g.pieces = pl.pieces; g.kb_per_piece = pl.per; g.partial = p.partial;
     const size_t lds = (size_t)36 * W4T * W4N * sizeof(float);
     if (mb == 2) {
         allow_big_lds(reinterpret_cast<const void *>(&wino4_gemm_kernel<2>), lds);
@@ -388,9 +485,15 @@ void wino4_launch(const ConvP &p, float *V, hipStream_t s, hipEvent_t *ev_in, hi
     } else {
         allow_big_lds(reinterpret_cast<const void *>(&wino4_gemm_kernel<1>), lds);
         if (ev_gemm)
-            hipExtLaunchKernelGGL(wino4_gemm_kernel<1>, dim3(tiles_m * tiles_n), dim3(64 * W4W), lds, s, ev_gemm[0], ev_gemm[1], 0, g, tiles_n);
+            hipExtLaunchKernelGGL(wino4_gemm_kernel<1>, dim3(grid), dim3(64 * W4W), lds, s, ev_gemm[0], ev_gemm[1], 0, g, tiles_n);
         else
-            hipLaunchKernelGGL(wino4_gemm_kernel<1>, dim3(tiles_m * tiles_n), dim3(64 * W4W), lds, s, g, tiles_n);
+            hipLaunchKernelGGL(wino4_gemm_kernel<1>, dim3(grid), dim3(64 * W4W), lds, s, g, tiles_n);
+        if (g.pieces > 1) {
+            if (ev_red)
+                hipExtLaunchKernelGGL(wino4_reduce_kernel, dim3((tiles_m * tiles_n - g.full_wg) * 64), dim3(256), 0, s, ev_red[0], ev_red[1], 0, g, tiles_n);
+            else
+                hipLaunchKernelGGL(wino4_reduce_kernel, dim3((tiles_m * tiles_n - g.full_wg) * 64), dim3(256), 0, s, g, tiles_n);
+        }
     }
 }
 

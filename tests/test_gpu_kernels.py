@@ -51,6 +51,9 @@ CONVS = [
     (1, 6, 5, 128, 32, 3, 1, 5, 0),
     (1, 120, 216, 256, 256, 3, 1, 5, 0),
     (2, 60, 108, 512, 256, 3, 1, 6, 0),
+    # ... and its tail split: 288 workgroups of 32 tiles x 32 channels = one round of 256 + 32 tiles cut into 8 K pieces each
+    (5, 30, 54, 512, 512, 3, 1, 6, 0),      # the 1/16-scale decoder layers over a 5-frame group
+    (2, 52, 78, 256, 512, 3, 1, 7, 0),      # with a residual, both ReLUs, ragged tiles (13 x 20 per image)
     # pointwise instance (1x1, stride 1): ragged M, residual + ReLU, split-K, and the stride-2 1x1 that must NOT take it
     (2, 19, 21, 256, 192, 1, 1, 2, 0),
     (1, 30, 54, 512, 128, 1, 1, 0, 3),
