@@ -285,6 +285,23 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvP p, const int
     }
     __syncthreads();
 
+    // Pointwise instance: the residual of the wave's accumulator block is requested HERE, before the K loop, not in the epilogue -
+    // the ResNet conv3 layers (64 -> 256, 128 -> 512, 256 -> 1024: 2 - 8 K tiles) are chains of dependent round trips otherwise
+    // (operands -> MFMAs -> residual -> store); with the residual in flight under the K loop they are one round trip shorter.
+    float rpre[16];
+    const bool res_pre = PW && p.res && p.affine_out && p.splitk == 1 && !piece;
+    if (PW) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rpre[r] = 0.f;
+        if (res_pre) {
+            const __amdgpu_buffer_rsrc_t rr0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.res), 0, (unsigned)((long)p.M * p.N * 4), 0x00020000);
+            const int n0 = tn * BN + wn * 32 + (lane & 31), mb0 = tm * BM + wm * 32 + 4 * (lane >> 5);
+            const unsigned v00 = n0 < p.N ? (unsigned)(((long)mb0 * p.N + n0) * 4) : OOB, n40 = (unsigned)p.N * 4u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                rpre[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr0, v00 + (unsigned)((r & 3) + 8 * (r >> 2)) * n40, 0, 0));
+        }
+    }
     const int arow = (wm * RM * 32 + (lane & 31)) * LDT + (lane >> 5) * 4;
     const int brow = (wn * RN * 32 + (lane & 31)) * LDT + (lane >> 5) * 4;
     constexpr int NPIECE = PA + PB;
@@ -378,7 +395,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvP p, const int
                 // loop hipcc waited vmcnt(0) per element - 16 serialized round trips per accumulator block, longer than the
                 // 8-K-tile MFMA body of the ResNet 1x1 convs that carry the residual.
                 float rv[16];
-                if (p.res) {
+                if (PW && res_pre) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rv[r] = rpre[r];
+                } else if (p.res) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
                         rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, v0 + (unsigned)((r & 3) + 8 * (r >> 2)) * n4, 0, 0));
@@ -543,7 +563,8 @@ static Plan plan_variant(const ConvP &p, bool big, int force_splitk, size_t ws_f
 void conv_plan(ConvP &p, int force_splitk, size_t ws_floats) {
     static const int big_mode = [] { const char *e = getenv("STCN_CONV_BIG"); return e ? atoi(e) : 1; }();
     Plan pl = plan_variant(p, false, force_splitk, ws_floats);
-    const bool big_ok = big_mode != 0 && !narrow_variant(p) && !smallc_variant(p) && p.N >= 256 && p.Kp >= 2304;
+    static const int big_mink = [] { const char *e = getenv("STCN_CONV_BIG_MINK"); return e ? atoi(e) : 2304; }();
+    const bool big_ok = big_mode != 0 && !narrow_variant(p) && !smallc_variant(p) && p.N >= 128 && p.Kp >= big_mink;
     if (big_ok) {
         const Plan pb = plan_variant(p, true, force_splitk, ws_floats);
         if (pb.cost < pl.cost || big_mode >= 2) pl = pb;
