@@ -98,7 +98,7 @@ static int upload(Model &m, const std::vector<float> &h, float **dev) {
 
 int make_wino(Model &m, ConvW &cw, const std::vector<float> &w) {
     static const bool on = [] { const char *e = getenv("STCN_WINOGRAD"); return !e || atoi(e) != 0; }();
-    if (!on || cw.kh != 3 || cw.kw != 3 || cw.cin_p % 32 || cw.cin_p < 128 || cw.cout % 64) return STCN_OK;
+    if (!on || cw.kh != 3 || cw.kw != 3 || cw.cin_p % 32 || cw.cin_p < wino_min_cin() || cw.cout % 64) return STCN_OK;
     std::vector<float> u((size_t)16 * cw.cin_p * cw.cout);
     wino_transform_weights(w.data(), cw.cout, cw.cin_p, cw.Kp, u.data());
     return upload(m, u, &cw.wino_u);
@@ -375,6 +375,8 @@ int run_conv(const Model &m, Work &w, hipStream_t s, const char *name, const flo
     const bool wino = wino_need > 0 && wino_need <= w.wino_v_floats;
     const double fl_exec = wino4 ? 2.0 * (double)wino4_need * p.N : (wino ? 2.0 * (double)(wino_need / cw.cin_p) * cw.cin_p * p.N : fl);
     hipEvent_t *eg = nullptr, *er = nullptr, *ei = nullptr;
+    hipEvent_t *eg4[16] = {}, *ei4[16] = {};                    // per chunk of a chunked F(4x4) launch
+    int n4 = 1;
     if (w.prof) {
         // algorithmic bytes: the input tensors (dense data, not the descriptor extents; a broadcast source once), weights,
         // output and residual (a broadcast residual once), each once
@@ -393,6 +395,9 @@ int run_conv(const Model &m, Work &w, hipStream_t s, const char *name, const flo
         eg = w.prof->attach(cls, hbm_acc);
         if (wino4) {
             ei = w.prof->attach(STCN_K_WINO_INPUT);
+            n4 = wino4_chunks(p, w.splitk_floats);
+            eg4[0] = eg; ei4[0] = ei;
+            for (int c = 1; c < n4; ++c) { eg4[c] = w.prof->attach(cls, hbm_acc); ei4[c] = w.prof->attach(STCN_K_WINO_INPUT); }
             if (wino4_tail_split(p, w.splitk_floats)) er = w.prof->attach(STCN_K_CONV_REDUCE);
         } else if (wino) {
             ei = w.prof->attach(STCN_K_WINO_INPUT);
@@ -402,7 +407,7 @@ int run_conv(const Model &m, Work &w, hipStream_t s, const char *name, const flo
         }
     }
     if (fus) fusion_conv_launch(p, s, eg);
-    else if (wino4) wino4_launch(p, w.wino_v, w.splitk_floats, s, ei, eg, er);
+    else if (wino4) wino4_launch(p, w.wino_v, w.splitk_floats, s, ei ? ei4 : nullptr, eg ? eg4 : nullptr, er);
     else if (wino) wino_launch(p, w.wino_v, w.splitk_floats, s, ei, eg, er);
     else conv_launch(p, s, eg, er);
     return launch_status(name);

@@ -74,14 +74,18 @@ void conv_launch(const ConvP &p, hipStream_t s, hipEvent_t *ev_gemm = nullptr, h
 void conv_reduce_launch(const ConvP &p, hipStream_t s, hipEvent_t *ev_red = nullptr);
 // Winograd F(2x2,3x3) path (winograd.hip): V workspace floats this conv needs, or 0 when it is not eligible
 size_t wino_workspace_floats(const ConvP &p);
+int wino_min_cin();
 void wino_launch(const ConvP &p, float *V, size_t slab_floats, hipStream_t s, hipEvent_t *ev_in = nullptr, hipEvent_t *ev_gemm = nullptr,
                  hipEvent_t *ev_red = nullptr);
 int wino_plan_splitk(const ConvP &p, size_t slab_floats);
 void wino_transform_weights(const float *w, int N, int Cin, int Kp, float *U);
 // Winograd F(4x4,3x3) path (winograd4.hip, decoder layers): V workspace floats, or 0 when not eligible / fewer than min_wg workgroups
 size_t wino4_workspace_floats(const ConvP &p, int min_wg);
-void wino4_launch(const ConvP &p, float *V, size_t slab_floats, hipStream_t s, hipEvent_t *ev_in = nullptr, hipEvent_t *ev_gemm = nullptr,
-                  hipEvent_t *ev_red = nullptr);
+// ev_in / ev_gemm: one {start, stop} pair per chunk (wino4_chunks: the transform and the GEMM alternate over slices of the tiles
+// when V would not stay in the memory-side cache)
+void wino4_launch(const ConvP &p, float *V, size_t slab_floats, hipStream_t s, hipEvent_t *const *ev_in = nullptr,
+                  hipEvent_t *const *ev_gemm = nullptr, hipEvent_t *ev_red = nullptr);
+int wino4_chunks(const ConvP &p, size_t slab_floats);
 // does wino4_launch cut the last round of this conv's workgroups into K pieces (a reduce launch follows)?
 bool wino4_tail_split(const ConvP &p, size_t slab_floats);
 void wino4_transform_weights(const float *w, int N, int Cin, int Kp, float *U);

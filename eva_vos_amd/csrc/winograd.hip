@@ -17,7 +17,7 @@
 //     (loop-invariant per-lane offsets + one scalar k-block offset: no address VALU), one k-block ahead.
 //     8 x 16-byte loads per 32 MFMAs = 16 B per CU-cycle from L2, the same as the 64x64 direct tile.
 //   * epilogue: the 16 positions of a tile meet in LDS (128 KB, 32 output channels at a time), Y = A^T M A, + bias / residual /
-//     ReLU, 128-byte coalesced stores.  Split-K over input channels (few tiles) writes transformed partial sums into the slabs
+//     ReLU; a work item owns 4 channels of one output row of a tile: 16-byte LDS reads, loads and stores.  Split-K over input channels (few tiles) writes transformed partial sums into the slabs
 //     of conv_reduce_kernel (the output transform is linear).
 #include <hip/hip_ext.h>
 
@@ -206,19 +206,29 @@ __global__ __launch_bounds__(1024 / PPW) void wino_gemm_kernel(const WinoG p, co
         if (k + 1 < nk) compute(fa1, fb1);
     }
 
-    // ---- epilogue: 32 output channels at a time through LDS, Y = A^T M A
-    constexpr int TS = NT / 32, NQ = WT / TS;                               // tiles per pass of the thread block, passes
-    const int n_l = t & 31, tsub = t >> 5;                                  // thread -> (channel, tiles tsub + TS q)
+    // ---- epilogue: 32 output channels at a time through LDS, Y = A^T M A.
+    // work item = (tile, 4 consecutive channels, output row): 16-byte LDS reads, residual loads and stores (the scalar
+    // one-channel-per-thread form spent more VALU cycles on addresses and 4-byte memory instructions than the transform needs);
+    // 64 x 8 x 2 items per channel half: one pass of the 16-wave instance, two of the 8-wave one.  Arithmetic order = the
+    // scalar form's: results are bit-identical to it.
+    constexpr int NQ = 1024 / NT;
+    const int chq = t & 7, tl = (t >> 3) & 63;
     const int tpi = p.TH * p.TW, ohw = p.OH * p.OW;
-    int tb[NQ], toh[NQ], tow[NQ];                                              // batch element and first output pixel of the 4 tiles
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const long gt = (long)tm * WT + tsub + TS * q;
-        const int b = gt < p.Mt ? fastdiv((int)gt, p.fd_tpi) : -1;
-        const int rr = (int)(gt - (long)(b < 0 ? 0 : b) * tpi);
-        const int ty = fastdiv(rr, p.fd_tw);
-        tb[q] = b; toh[q] = 2 * ty; tow[q] = 2 * (rr - ty * p.TW);
-    }
+    const bool part = p.splitk > 1;
+    // residual / output through buffer resources: 32-bit byte offsets (extents < 4 GiB: wino_workspace_floats); a masked store
+    // is an out-of-range offset
+    const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.res ? p.res : p.y), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(part ? p.partial : p.y, 0, -1, 0x00020000);
+    const long gt = (long)tm * WT + tl;
+    const bool work = gt < p.Mt;
+    const int gtc = (int)min(gt, (long)p.Mt - 1);
+    const int b = fastdiv(gtc, p.fd_tpi);
+    const int rr = gtc - b * tpi;
+    const int ty = fastdiv(rr, p.fd_tw), tx = rr - ty * p.TW;
+    const unsigned ybase = part ? (unsigned)(((long)split * p.M + (long)b * ohw) * p.N) * 4u
+                                : (unsigned)b * (unsigned)(p.y_bs ? p.y_bs : (long)ohw * p.N) * 4u;
+    const unsigned rbase = (unsigned)(p.res_bmod ? b % p.res_bmod : b) * (unsigned)p.res_bs * 4u;
+    const float lo = (p.relu_out && !part) ? 0.f : -__builtin_inff();
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         __syncthreads();
@@ -229,49 +239,56 @@ __global__ __launch_bounds__(1024 / PPW) void wino_gemm_kernel(const WinoG p, co
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     smem[((pos0 + pi) * WT + 32 * bi + (r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l31] = acc[pi][bi][c][r];
-        __syncthreads();
-        const int n = tn * WN + 32 * c + n_l;
-        const float bv = (p.bias && p.splitk == 1) ? p.bias[n] : 0.f;
+        const int n = tn * WN + 32 * c + 4 * chq;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias && !part) bv = *reinterpret_cast<const f32x4 *>(p.bias + n);
+        // the residual block of all passes is requested before the barrier (offsets clamped inside the image for the ragged last
+        // tile row / column)
+        unsigned po[NQ][2];
+        f32x4 rv[NQ][2];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const int tl = tsub + TS * q;
-            float m[16];
+            const int row = NQ == 1 ? (t >> 9) : q;
 #pragma unroll
-            for (int ps = 0; ps < 16; ++ps) m[ps] = smem[(ps * WT + tl) * 32 + n_l];
-            const int b = tb[q];
-            if (b < 0) continue;
-            // rows of M are the vertical index xi: pos = 4 xi + nu
-            float u0[4], u1[4];
+            for (int e = 0; e < 2; ++e)
+                po[q][e] = (unsigned)((min(2 * ty + row, p.OH - 1) * p.OW + min(2 * tx + e, p.OW - 1)) * p.N + n) * 4u;
+        }
+        if (p.res && !part) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+                    rv[q][e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, rbase + po[q][e], 0, 0));
+        } else {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) rv[q][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        __syncthreads();
+        if (!work) continue;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int row = NQ == 1 ? __builtin_amdgcn_readfirstlane(t >> 9) : q;
+            // rows of M are the vertical index xi: pos = 4 xi + nu.  Output row 0: u = m[0] + m[1] + m[2]; row 1: u = m[1] - m[2] - m[3]
+            const f32x4 *sm4 = reinterpret_cast<const f32x4 *>(smem) + tl * 8 + chq;
+            f32x4 u[4];
 #pragma unroll
             for (int nu = 0; nu < 4; ++nu) {
-                u0[nu] = m[nu] + m[4 + nu] + m[8 + nu];
-                u1[nu] = m[4 + nu] - m[8 + nu] - m[12 + nu];
+                const f32x4 ma = sm4[((row * 4 + nu) * WT) * 8], mb = sm4[(((row + 1) * 4 + nu) * WT) * 8],
+                            mc = sm4[(((row + 2) * 4 + nu) * WT) * 8];
+                u[nu] = row ? ma - mb - mc : ma + mb + mc;
             }
-            const float yv[2][2] = {{u0[0] + u0[1] + u0[2], u0[1] - u0[2] - u0[3]}, {u1[0] + u1[1] + u1[2], u1[1] - u1[2] - u1[3]}};
-            const float *resb = p.res ? p.res + (long)(p.res_bmod ? b % p.res_bmod : b) * p.res_bs + n : nullptr;
-            float *yb = p.splitk > 1 ? p.partial + ((long)split * p.M + (long)b * ohw) * p.N + n
-                                     : p.y + (p.y_bs ? (long)b * p.y_bs : (long)b * ohw * p.N) + n;
-            // offsets (clamped inside the image for the ragged last tile row / column), then the 4 residual values TOGETHER (a load
-            // behind `if (resb)` per output made hipcc drain vmcnt per element), then the stores
-            long po[4];
-            float rv[4];
+            const f32x4 yv[2] = {u[0] + u[1] + u[2], u[1] - u[2] - u[3]};
+            const bool rok = 2 * ty + row < p.OH;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) po[e] = ((long)min(toh[q] + (e >> 1), p.OH - 1) * p.OW + min(tow[q] + (e & 1), p.OW - 1)) * p.N;
-            if (resb && p.splitk == 1) {
+            for (int e = 0; e < 2; ++e) {
+                f32x4 v = yv[e] + bv + rv[q][e];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) rv[e] = resb[po[e]];
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) rv[e] = 0.f;
-            }
-            const float lo = (p.relu_out && p.splitk == 1) ? 0.f : -__builtin_inff();
-            float ov[4];                                                  // values first (one wait), masked stores after
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { ov[e] = fmaxf(yv[e >> 1][e & 1] + (p.splitk == 1 ? bv : 0.f) + rv[e], lo); asm volatile("" : "+v"(ov[e])); }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (toh[q] + (e >> 1) >= p.OH || tow[q] + (e & 1) >= p.OW) continue;
-                yb[po[e]] = ov[e];
+                for (int c4 = 0; c4 < 4; ++c4) v[c4] = fmaxf(v[c4], lo);
+                const bool ok = rok && 2 * tx + e < p.OW;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v), ry,
+                                                       ok ? ybase + po[q][e] : 0xFFFFFFFFu, 0, 0);
             }
         }
     }
@@ -283,13 +300,24 @@ static bool wino_enabled() {
     return on;
 }
 
+// fewest input channels worth the transforms (STCN_WINO_MIN_CIN)
+int wino_min_cin() {
+    static const int v = [] { const char *e = getenv("STCN_WINO_MIN_CIN"); return e ? atoi(e) : 64; }();
+    return v;
+}
+
 // floats of V workspace the Winograd path needs for this conv (0: not eligible)
 size_t wino_workspace_floats(const ConvP &p) {
     if (!wino_enabled() || !p.wino_u || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.x1) return 0;
-    if (p.Cin % 32 || p.Cin < 128 || p.N % WN || p.bs0 == 0) return 0;    // 64-channel layers: the transforms cost more than they save
+    if (p.Cin % 32 || p.Cin < wino_min_cin() || p.N % WN || p.bs0 == 0) return 0;
     const long Mt = (long)p.B * ((p.OH + 1) / 2) * ((p.OW + 1) / 2);
     const long Mt_pad = (Mt + WT - 1) / WT * WT;
+    // 64-channel layers (K = 8 k-blocks): the transforms and the epilogue outweigh the MFMA saving unless the launch is large -
+    // 64 -> 64 at 120x216: 94 -> 76 us over a 5-frame group (32400 tiles), 26 -> 32 us for one frame (6480 tiles)
+    if (p.Cin < 128 && Mt < 16384) return 0;
     if (16L * p.Cin * Mt_pad * 4 >= (1L << 32)) return 0;                  // 32-bit buffer offsets
+    if ((long)p.B * (p.y_bs ? p.y_bs : (long)p.OH * p.OW * p.N) * 4 >= (1L << 32)) return 0;
+    if (p.res && (long)(p.res_bmod ? p.res_bmod : p.B) * p.res_bs * 4 >= (1L << 32)) return 0;
     return (size_t)16 * p.Cin * Mt_pad;
 }
 

@@ -20,11 +20,13 @@
 // 12 waves x 3 positions x ONE 32x32 accumulator block; per k-block of 8 channels a wave loads 3 A and 3 B fragments (1 KB each,
 // contiguous: V / U are laid out [position][C/8][row][8]) for 12 MFMAs - twice the L2 bytes per MFMA of the F(2x2) kernel, the
 // unavoidable cost of the small tile - two k-blocks ahead, pinned with sched_barrier.  Epilogue: 36 x 32 x 32 floats = 144 KB
-// of LDS, each thread gathers the 36 positions of (tile, channel), A^T M A, bias / residual / ReLU, 128-byte stores.
+// of LDS; a thread gathers the 36 positions of (tile, 4 channels) with 16-byte reads and produces two of the four output
+// columns: A^T M A, bias / residual / ReLU, 16-byte buffer stores.
 #include <hip/hip_ext.h>
 
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "kernels.h"
 
@@ -55,15 +57,15 @@ __device__ __forceinline__ void bt6(const f32x4 &d0, const f32x4 &d1, const f32x
 // 128-byte line of a pixel; stores are 256-byte runs of V per position.
 __global__ __launch_bounds__(256) void wino4_input_kernel(const float *__restrict__ x, unsigned x_bytes, long x_bs, int H, int W, int C,
                                                           int relu_in, int TH, int TW, int Mt, int Mt_pad, int cb_per_chunk,
-                                                          float *__restrict__ V) {
+                                                          int tile_lo, int tile_hi, float *__restrict__ V) {
     // XCD-contiguous block order: neighbouring tile rows share two pixel rows; dealt round-robin over the XCDs (the dispatcher's
     // order) those rows were fetched into two L2s - FETCH_SIZE 2.1x the input
     const int nbx = gridDim.x, q8 = nbx >> 3, r8 = nbx & 7, xcd = blockIdx.x & 7;
     const int bx = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
     const long i = bx * 256L + threadIdx.x;
     const int c16 = (int)(i & 7);
-    const long tile = i >> 3;
-    if (tile >= Mt_pad) return;
+    const long tile = tile_lo + (i >> 3);                    // [tile_lo, tile_hi): the launch's slice of the tiles (whole V when not chunked)
+    if (tile >= tile_hi) return;
     const int KB = C / 8, NCB = C / 32;
     const int cb0 = blockIdx.y * cb_per_chunk, cb1 = min(NCB, cb0 + cb_per_chunk);
     const bool live = tile < Mt;
@@ -129,6 +131,7 @@ struct Wino4G {
     // [(tile - full_wg) * pieces + piece][32 tiles][16 pixels][32 channels] and are summed by wino4_reduce_kernel
     int full_wg, pieces, kb_per_piece;
     float *partial;
+    int tm0;                                   // first tile block of this launch (chunked launches, MB = 2)
 };
 
 // MB = 32-tile blocks per workgroup.  MB = 1: three fragment sets, loads two k-blocks ahead.  MB = 2 (64 tiles x 32 channels: 25 %
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(64 * W4W) void wino4_gemm_kernel(const Wino4G p, co
     } else {
         swz = xcd_contiguous(blockIdx.x, MB == 1 && p.pieces > 1 ? p.full_wg : (int)gridDim.x);
     }
-    const int tm = fastdiv(swz, p.fd_tiles_n), tn = swz - tm * tiles_n;
+    const int tm_l = fastdiv(swz, p.fd_tiles_n), tn = swz - tm_l * tiles_n, tm = tm_l + p.tm0;
     const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);                  // wave-uniform: the position offsets below stay in SGPRs
     const int pos0 = PPW * wave;
@@ -271,93 +274,130 @@ __global__ __launch_bounds__(64 * W4W) void wino4_gemm_kernel(const Wino4G p, co
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    // ---- epilogue, 32 tiles at a time: all 36 positions of 32 x 32 (tile, channel) pairs meet in LDS, Y = A^T M A
-    const int n_l = t & 31, tsub = t >> 5;                                    // thread -> (channel, tiles tsub, tsub + 24)
+    // ---- epilogue, 32 tiles at a time: all 36 positions of 32 x 32 (tile, channel) pairs meet in LDS, Y = A^T M A.
+    // thread = (tile, 4 consecutive channels, half of the output columns): 16-byte LDS reads, residual loads and stores; the
+    // first 8 waves work (32 tiles x 8 channel quads x 2 column pairs).  The residual block (+ bias) is requested before the
+    // barrier - after the accumulators went to LDS, their registers are free - and is the start value of the output sums.
+    const int chq = t & 7, tl = (t >> 3) & 31;
+    const int jh = __builtin_amdgcn_readfirstlane(t >> 8);                    // wave-uniform: output columns 2 jh, 2 jh + 1
     const int tpi = p.TH * p.TW, ohw = p.OH * p.OW;
-    const int n = tn * W4N + n_l;
-    const float bv = p.bias ? p.bias[n] : 0.f;
+    const int n = tn * W4N + 4 * chq;
+    const bool kpiece = MB == 1 && piece >= 0;
+    const float lo = p.relu_out ? 0.f : -__builtin_inff();
+    // residual / output through buffer resources: 32-bit byte offsets (extents < 4 GiB: wino4_workspace_floats), a masked store is
+    // an out-of-range offset
+    const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.res ? p.res : p.y), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, -1, 0x00020000);
+    const unsigned y_bs = (unsigned)(p.y_bs ? p.y_bs : (long)ohw * p.N);
 #pragma unroll
     for (int half = 0; half < MB; ++half) {
+        int toff = 32 * half + tl;
+        asm volatile("" : "+v"(toff));                                        // the index math of the second half stays behind the first
+        const long gt = (long)tm * WT + toff;
+        const bool work = jh < 2 && gt < p.Mt;
+        const int gtc = (int)min(gt, (long)p.Mt - 1);
+        const int b = fastdiv(gtc, p.fd_tpi);
+        const int rr = gtc - b * tpi;
+        const int ty = fastdiv(rr, p.fd_tw), tx = rr - ty * p.TW;
+        unsigned prow[4], pcol[2];                                            // byte offsets inside the image; ragged tiles: clamped, stores masked
+#pragma unroll
+        for (int i2 = 0; i2 < 4; ++i2) prow[i2] = (unsigned)(min(4 * ty + i2, p.OH - 1) * p.OW * p.N) * 4u;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) pcol[j] = (unsigned)(min(4 * tx + 2 * jh + j, p.OW - 1) * p.N + n) * 4u;
         if (half) __syncthreads();
 #pragma unroll
         for (int pi = 0; pi < PPW; ++pi)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 smem[((pos0 + pi) * W4T + (r & 3) + 8 * (r >> 2) + 4 * h) * W4N + l31] = acc[pi][half][r];
-        __syncthreads();
-#pragma unroll 1
-        for (int q = 0; q < 2; ++q) {
-            const int tl = tsub + 24 * q;
-            if (tl >= W4T) break;
-            const long gt = (long)tm * WT + 32 * half + tl;
-            if (gt >= p.Mt) continue;
-            const int b = fastdiv((int)gt, p.fd_tpi);
-            const int rr = (int)(gt - (long)b * tpi);
-            const int ty = fastdiv(rr, p.fd_tw), tx = rr - ty * p.TW;
-            // rows of M are the vertical index xi: pos = 6 xi + nu.  First the transform along nu (6 -> 4 per xi), then along xi.
-            float z[6][4];
+        f32x4 yv[2][4], bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias && !kpiece) {
+            int nb = n;
+            asm volatile("" : "+v"(nb));                                      // per half: four registers not live across the other half
+            bv = *reinterpret_cast<const f32x4 *>(p.bias + nb);
+        }
+        if (p.res && !kpiece && jh < 2) {
+            const unsigned rb = (unsigned)(p.res_bmod ? b % p.res_bmod : b) * (unsigned)p.res_bs * 4u;
 #pragma unroll
-            for (int xi = 0; xi < 6; ++xi) {
-                float m[6];
-#pragma unroll
-                for (int nu = 0; nu < 6; ++nu) m[nu] = smem[((xi * 6 + nu) * W4T + tl) * W4N + n_l];
-                const float s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
-                z[xi][0] = m[0] + s12 + s34;
-                z[xi][1] = d12 * 0.75f + d34 * 1.5f;
-                z[xi][2] = s12 * 0.5625f + s34 * 2.25f;
-                z[xi][3] = d12 * 0.421875f + d34 * 3.375f + m[5];            // 27/64, 27/8
-            }
-            if (MB == 1 && piece >= 0) {
-                // K piece: the 16 outputs of (tile, channel) of THIS k range, no bias / residual / ReLU, into the tile-local slab
-                float *dst = p.partial + (((long)(swz - p.full_wg) * p.pieces + piece) * W4T + tl) * (16 * W4N) + n_l;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float s12 = z[1][j] + z[2][j], d12 = z[1][j] - z[2][j], s34 = z[3][j] + z[4][j], d34 = z[3][j] - z[4][j];
-                    dst[(0 * 4 + j) * W4N] = z[0][j] + s12 + s34;
-                    dst[(1 * 4 + j) * W4N] = d12 * 0.75f + d34 * 1.5f;
-                    dst[(2 * 4 + j) * W4N] = s12 * 0.5625f + s34 * 2.25f;
-                    dst[(3 * 4 + j) * W4N] = d12 * 0.421875f + d34 * 3.375f + z[5][j];
-                }
-                continue;
-            }
-            const float *resb = p.res ? p.res + (long)(p.res_bmod ? b % p.res_bmod : b) * p.res_bs + n : nullptr;
-            float *yb = p.y + (p.y_bs ? (long)b * p.y_bs : (long)b * ohw * p.N) + n;
-            // the 16 residual values of the tile are requested TOGETHER, before the column transform (a load behind `if (resb)`
-            // per output made hipcc drain vmcnt per element); ragged tiles: offsets clamped inside the image, stores masked
-            float rv[4][4];
-            int po[4][4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int i2 = 0; i2 < 4; ++i2) po[j][i2] = (min(4 * ty + i2, p.OH - 1) * p.OW + min(4 * tx + j, p.OW - 1)) * p.N;
-            if (resb) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int i2 = 0; i2 < 4; ++i2) rv[j][i2] = resb[po[j][i2]];
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int i2 = 0; i2 < 4; ++i2) rv[j][i2] = 0.f;
-            }
-            const float lo = p.relu_out ? 0.f : -__builtin_inff();
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float s12 = z[1][j] + z[2][j], d12 = z[1][j] - z[2][j], s34 = z[3][j] + z[4][j], d34 = z[3][j] - z[4][j];
-                const float yv[4] = {z[0][j] + s12 + s34, d12 * 0.75f + d34 * 1.5f, s12 * 0.5625f + s34 * 2.25f,
-                                     d12 * 0.421875f + d34 * 3.375f + z[5][j]};
-#pragma unroll
-                for (int i2 = 0; i2 < 4; ++i2) { rv[j][i2] = fmaxf(yv[i2] + bv + rv[j][i2], lo); asm volatile("" : "+v"(rv[j][i2])); }   // values first, pinned
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {                                     // masked stores after the one wait for the residual loads
-                if (4 * tx + j >= p.OW) continue;
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int i2 = 0; i2 < 4; ++i2)
-                    if (4 * ty + i2 < p.OH) yb[po[j][i2]] = rv[j][i2];
-            }
+                    yv[j][i2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, rb + prow[i2] + pcol[j], 0, 0));
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i2 = 0; i2 < 4; ++i2) yv[j][i2] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        __syncthreads();
+        if (!work) continue;
+        // rows of M are the vertical index xi: pos = 6 xi + nu.  Per row the transform along nu (6 -> this thread's 2 columns), then
+        // along xi (6 -> 4 rows) as running sums (one z row live at a time): A^T = [1 1 1 1 1 0; 0 a -a b -b 0; 0 a^2 a^2 b^2 b^2 0; 0 a^3 -a^3 b^3 -b^3 1],
+        // a = 3/4, b = 3/2
+        auto zrow = [&](int xi, auto JH, f32x4 (&zr)[2]) {
+            f32x4 m[6];
+            int ro4 = (xi * 6 * W4T + tl) * (W4N / 4) + chq;                  // in 16-byte units: the alignment survives the pin
+            asm volatile("" : "+v"(ro4));                                     // one address register per row, not 20 hoisted ones
+#pragma unroll
+            for (int nu = 0; nu < 6; ++nu) m[nu] = reinterpret_cast<const f32x4 *>(smem)[ro4 + nu * W4T * (W4N / 4)];
+            if (decltype(JH)::value == 0) {
+                zr[0] = m[0] + (m[1] + m[2]) + (m[3] + m[4]);
+                zr[1] = (m[1] - m[2]) * 0.75f + (m[3] - m[4]) * 1.5f;
+            } else {
+                zr[0] = (m[1] + m[2]) * 0.5625f + (m[3] + m[4]) * 2.25f;
+                zr[1] = (m[1] - m[2]) * 0.421875f + (m[3] - m[4]) * 3.375f + m[5];     // 27/64, 27/8
+            }
+        };
+        auto columns = [&](auto JH) {
+            f32x4 za[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i2 = 0; i2 < 4; ++i2) yv[j][i2] += bv;
+            zrow(0, JH, za);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) yv[j][0] += za[j];
+            constexpr float c1[4] = {0.75f, -0.75f, 1.5f, -1.5f}, c2[4] = {0.5625f, 0.5625f, 2.25f, 2.25f},
+                            c3[4] = {0.421875f, -0.421875f, 3.375f, -3.375f};            // 27/64, 27/8
+#pragma unroll
+            for (int xi = 1; xi < 5; ++xi) {
+                __builtin_amdgcn_sched_barrier(0);                            // keep the LDS reads of later rows behind (registers)
+                zrow(xi, JH, za);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    yv[j][0] += za[j];
+                    yv[j][1] += za[j] * c1[xi - 1];
+                    yv[j][2] += za[j] * c2[xi - 1];
+                    yv[j][3] += za[j] * c3[xi - 1];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            zrow(5, JH, za);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) yv[j][3] += za[j];
+        };
+        if (jh == 0) columns(std::integral_constant<int, 0>{});
+        else columns(std::integral_constant<int, 1>{});
+        if (kpiece) {
+            // K piece: the outputs of (tile, channels) of THIS k range, no bias / residual / ReLU, into the tile-local slab
+            float *dst = p.partial + (((long)(swz - p.full_wg) * p.pieces + piece) * W4T + tl) * (16 * W4N) + 4 * chq;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i2 = 0; i2 < 4; ++i2) *reinterpret_cast<f32x4 *>(dst + (i2 * 4 + 2 * jh + j) * W4N) = yv[j][i2];
+            continue;
+        }
+        const unsigned yb = (unsigned)b * y_bs * 4u;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i2 = 0; i2 < 4; ++i2) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) yv[j][i2][c] = fmaxf(yv[j][i2][c], lo);
+                const bool ok = 4 * tx + 2 * jh + j < p.OW && 4 * ty + i2 < p.OH;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, yv[j][i2]), ry,
+                                                       ok ? yb + prow[i2] + pcol[j] : 0xFFFFFFFFu, 0, 0);
+            }
     }
 }
 
@@ -404,12 +444,14 @@ size_t wino4_workspace_floats(const ConvP &p, int min_wg) {
     const long Mt = (long)p.B * ((p.OH + 3) / 4) * ((p.OW + 3) / 4);
     const long Mt_pad = (Mt + 2 * W4T - 1) / (2 * W4T) * (2 * W4T);          // whole 64-tile workgroup tiles
     if (36L * p.Cin * Mt_pad * 4 >= (1L << 32)) return 0;                   // 32-bit buffer offsets
+    if ((long)p.B * (p.y_bs ? p.y_bs : (long)p.OH * p.OW * p.N) * 4 >= (1L << 32)) return 0;
+    if (p.res && (long)(p.res_bmod ? p.res_bmod : p.B) * p.res_bs * 4 >= (1L << 32)) return 0;
     if (wino4_mode() < 2 && (Mt_pad / W4T) * (p.N / W4N) < min_wg) return 0;  // too few workgroups: F(2x2) with its split-K is better
     return (size_t)36 * p.Cin * Mt_pad;
 }
 
 // launch plan of the F(4x4) GEMM: 64- or 32-tile workgroups, and (32-tile only) the tail split
-struct W4Plan { int Mt, Mt_pad, tiles_m, tiles_n, mb, grid, full_wg, pieces, per; };
+struct W4Plan { int Mt, Mt_pad, tiles_m, tiles_n, mb, grid, full_wg, pieces, per, chunks, tm_per_chunk; };
 static W4Plan wino4_plan(const ConvP &p, size_t slab_floats) {
     static const int mb_env = [] { const char *e = getenv("STCN_WINO4_MB"); return e ? atoi(e) : 0; }();
     static const bool tail_on = [] { const char *e = getenv("STCN_WINO4_TAIL"); return !e || atoi(e) != 0; }();
@@ -442,28 +484,32 @@ static W4Plan wino4_plan(const ConvP &p, size_t slab_floats) {
             }
         }
     }
+    // Chunked launches (64-tile workgroups): V of the 1/4-scale decoder layers over a 5-frame group is 299 MB - written by the
+    // transform, it has left the 256 MB memory-side cache before the GEMM reads it, and the GEMM's loads (one half-step ahead)
+    // then see HBM latency: 97-99 us per round of workgroups instead of 89 (measured at 75 / 151 / 302 / 604 MB of V).  Transform
+    // and GEMM alternate over slices of whole rounds whose V stays under ~160 MB.
+    pl.chunks = 1; pl.tm_per_chunk = pl.tiles_m;
+    const char *ce = getenv("STCN_WINO4_CHUNK_MB");                            // read per launch: tests run shapes under tiny chunks
+    const long chunk_bytes = (long)(ce ? atoi(ce) : 160) << 20;
+    const long vbytes = 36L * p.Cin * pl.Mt_pad * 4;
+    if (pl.mb == 2 && chunk_bytes > 0 && vbytes > chunk_bytes * 3 / 2) {
+        const int rounds = (pl.grid + cus - 1) / cus;
+        const int n = (int)((vbytes + chunk_bytes - 1) / chunk_bytes);
+        const int rpc = (rounds + n - 1) / n;
+        int tmpc = rpc * cus / pl.tiles_n;
+        tmpc = tmpc < 1 ? 1 : tmpc;
+        if (tmpc < pl.tiles_m && (pl.tiles_m + tmpc - 1) / tmpc <= 16) { pl.tm_per_chunk = tmpc; pl.chunks = (pl.tiles_m + tmpc - 1) / tmpc; }
+    }
     return pl;
 }
+int wino4_chunks(const ConvP &p, size_t slab_floats) { return wino4_plan(p, slab_floats).chunks; }
 bool wino4_tail_split(const ConvP &p, size_t slab_floats) { return wino4_plan(p, slab_floats).pieces > 1; }
 
-void wino4_launch(const ConvP &p, float *V, size_t slab_floats, hipStream_t s, hipEvent_t *ev_in, hipEvent_t *ev_gemm, hipEvent_t *ev_red) {
+void wino4_launch(const ConvP &p, float *V, size_t slab_floats, hipStream_t s, hipEvent_t *const *ev_in, hipEvent_t *const *ev_gemm,
+                  hipEvent_t *ev_red) {
     const W4Plan pl = wino4_plan(p, slab_floats);
     const int TH = (p.OH + 3) / 4, TW = (p.OW + 3) / 4;
     const int Mt = pl.Mt, Mt_pad = pl.Mt_pad, KB = p.Cin / 8;
-    {
-        const unsigned gx = (unsigned)((8L * Mt_pad + 255) / 256);
-        const int NCB = p.Cin / 32;
-        int chunks = (int)((2048 + gx - 1) / gx);
-        chunks = chunks < 1 ? 1 : (chunks > NCB ? NCB : chunks);
-        const int per = (NCB + chunks - 1) / chunks;
-        chunks = (NCB + per - 1) / per;
-        if (ev_in)
-            hipExtLaunchKernelGGL(wino4_input_kernel, dim3(gx, chunks), dim3(256), 0, s, ev_in[0], ev_in[1], 0, p.x0, p.x0_bytes, p.bs0, p.H, p.W,
-                                  p.Cin, p.relu_in, TH, TW, Mt, Mt_pad, per, V);
-        else
-            hipLaunchKernelGGL(wino4_input_kernel, dim3(gx, chunks), dim3(256), 0, s, p.x0, p.x0_bytes, p.bs0, p.H, p.W, p.Cin, p.relu_in, TH, TW,
-                               Mt, Mt_pad, per, V);
-    }
     Wino4G g{};
     g.V = V; g.U = p.wino4_u;
     g.v_bytes = (unsigned)((size_t)36 * p.Cin * Mt_pad * 4);
@@ -471,28 +517,48 @@ void wino4_launch(const ConvP &p, float *V, size_t slab_floats, hipStream_t s, h
     g.Mt = Mt; g.Mt_pad = Mt_pad; g.KB = KB; g.N = p.N;
     g.TH = TH; g.TW = TW; g.OH = p.OH; g.OW = p.OW; g.B = p.B; g.M = p.M;
     g.bias = p.bias; g.res = p.res; g.res_bs = p.res_bs; g.res_bmod = p.res_bmod; g.y = p.y; g.y_bs = p.y_bs; g.relu_out = p.relu_out;
-    // 64-tile workgroups (25 % fewer L2 bytes per MFMA: +6 % at 1/4 and 1/8 scale) unless they would leave CUs idle
-    const int tiles_n = pl.tiles_n, mb = pl.mb, tiles_m = pl.tiles_m, grid = pl.grid;
+    const int tiles_n = pl.tiles_n, mb = pl.mb, tiles_m = pl.tiles_m;
     g.fd_tpi = fastdiv_make((unsigned)(TH * TW)); g.fd_tw = fastdiv_make((unsigned)TW); g.fd_tiles_n = fastdiv_make((unsigned)tiles_n);
     g.full_wg = pl.full_wg; g.pieces = pl.pieces; g.kb_per_piece = pl.per; g.partial = p.partial;
     const size_t lds = (size_t)36 * W4T * W4N * sizeof(float);
-    if (mb == 2) {
-        allow_big_lds(reinterpret_cast<const void *>(&wino4_gemm_kernel<2>), lds);
-        if (ev_gemm)
-            hipExtLaunchKernelGGL(wino4_gemm_kernel<2>, dim3(tiles_m * tiles_n), dim3(64 * W4W), lds, s, ev_gemm[0], ev_gemm[1], 0, g, tiles_n);
-        else
-            hipLaunchKernelGGL(wino4_gemm_kernel<2>, dim3(tiles_m * tiles_n), dim3(64 * W4W), lds, s, g, tiles_n);
-    } else {
-        allow_big_lds(reinterpret_cast<const void *>(&wino4_gemm_kernel<1>), lds);
-        if (ev_gemm)
-            hipExtLaunchKernelGGL(wino4_gemm_kernel<1>, dim3(grid), dim3(64 * W4W), lds, s, ev_gemm[0], ev_gemm[1], 0, g, tiles_n);
-        else
-            hipLaunchKernelGGL(wino4_gemm_kernel<1>, dim3(grid), dim3(64 * W4W), lds, s, g, tiles_n);
-        if (g.pieces > 1) {
-            if (ev_red)
-                hipExtLaunchKernelGGL(wino4_reduce_kernel, dim3((tiles_m * tiles_n - g.full_wg) * 64), dim3(256), 0, s, ev_red[0], ev_red[1], 0, g, tiles_n);
+    for (int c = 0; c < pl.chunks; ++c) {
+        const int tm_lo = c * pl.tm_per_chunk, tm_hi = tm_lo + pl.tm_per_chunk < tiles_m ? tm_lo + pl.tm_per_chunk : tiles_m;
+        const int tile_lo = tm_lo * W4T * mb, tile_hi = pl.chunks == 1 ? Mt_pad : tm_hi * W4T * mb;
+        hipEvent_t *ei = ev_in ? ev_in[c] : nullptr, *eg = ev_gemm ? ev_gemm[c] : nullptr;
+        {
+            const unsigned gx = (unsigned)((8L * (tile_hi - tile_lo) + 255) / 256);
+            const int NCB = p.Cin / 32;
+            int chunks = (int)((2048 + gx - 1) / gx);
+            chunks = chunks < 1 ? 1 : (chunks > NCB ? NCB : chunks);
+            const int per = (NCB + chunks - 1) / chunks;
+            chunks = (NCB + per - 1) / per;
+            if (ei)
+                hipExtLaunchKernelGGL(wino4_input_kernel, dim3(gx, chunks), dim3(256), 0, s, ei[0], ei[1], 0, p.x0, p.x0_bytes, p.bs0, p.H, p.W,
+                                      p.Cin, p.relu_in, TH, TW, Mt, Mt_pad, per, tile_lo, tile_hi, V);
             else
-                hipLaunchKernelGGL(wino4_reduce_kernel, dim3((tiles_m * tiles_n - g.full_wg) * 64), dim3(256), 0, s, g, tiles_n);
+                hipLaunchKernelGGL(wino4_input_kernel, dim3(gx, chunks), dim3(256), 0, s, p.x0, p.x0_bytes, p.bs0, p.H, p.W, p.Cin, p.relu_in, TH,
+                                   TW, Mt, Mt_pad, per, tile_lo, tile_hi, V);
+        }
+        g.tm0 = tm_lo;
+        if (mb == 2) {
+            const int grid = (tm_hi - tm_lo) * tiles_n;
+            allow_big_lds(reinterpret_cast<const void *>(&wino4_gemm_kernel<2>), lds);
+            if (eg)
+                hipExtLaunchKernelGGL(wino4_gemm_kernel<2>, dim3(grid), dim3(64 * W4W), lds, s, eg[0], eg[1], 0, g, tiles_n);
+            else
+                hipLaunchKernelGGL(wino4_gemm_kernel<2>, dim3(grid), dim3(64 * W4W), lds, s, g, tiles_n);
+        } else {
+            allow_big_lds(reinterpret_cast<const void *>(&wino4_gemm_kernel<1>), lds);
+            if (eg)
+                hipExtLaunchKernelGGL(wino4_gemm_kernel<1>, dim3(pl.grid), dim3(64 * W4W), lds, s, eg[0], eg[1], 0, g, tiles_n);
+            else
+                hipLaunchKernelGGL(wino4_gemm_kernel<1>, dim3(pl.grid), dim3(64 * W4W), lds, s, g, tiles_n);
+            if (g.pieces > 1) {
+                if (ev_red)
+                    hipExtLaunchKernelGGL(wino4_reduce_kernel, dim3((tiles_m * tiles_n - g.full_wg) * 64), dim3(256), 0, s, ev_red[0], ev_red[1], 0, g, tiles_n);
+                else
+                    hipLaunchKernelGGL(wino4_reduce_kernel, dim3((tiles_m * tiles_n - g.full_wg) * 64), dim3(256), 0, s, g, tiles_n);
+            }
         }
     }
 }

@@ -38,6 +38,7 @@ CONVS = [
     (1, 31, 45, 256, 64, 3, 1, 0, 0),
     (3, 16, 20, 512, 192, 3, 1, 2, 0),
     (1, 6, 5, 128, 64, 3, 1, 1, 0),         # 9 tiles in one padded workgroup tile, split over input channels
+    (5, 120, 216, 64, 64, 3, 1, 3, 0),      # 64 channels run F(2x2) only in large launches: layer1 of the key encoder over a 5-frame group
     # Cin = 1024: the 8-wave instance (2 positions per wave) by default; few tiles -> split over input channels (key_proj: N = 64,
     # key_comp: N = 512), batch 2 -> residual + modulo-free batch stride in the Winograd epilogue and in the split-K reduce
     (1, 14, 18, 1024, 64, 3, 1, 0, 0),
@@ -54,6 +55,9 @@ CONVS = [
     # ... and its tail split: 288 workgroups of 32 tiles x 32 channels = one round of 256 + 32 tiles cut into 8 K pieces each
     (5, 30, 54, 512, 512, 3, 1, 6, 0),      # the 1/16-scale decoder layers over a 5-frame group
     (2, 52, 78, 256, 512, 3, 1, 7, 0),      # with a residual, both ReLUs, ragged tiles (13 x 20 per image)
+    # ... and its chunked launches (transform / GEMM alternate over slices of whole rounds): 408 workgroups of 64 tiles, run a
+    # second time under STCN_WINO4_CHUNK_MB=1 = two slices (32 + 19 tile blocks)
+    (2, 120, 216, 128, 256, 3, 1, 7, 0),
     # pointwise instance (1x1, stride 1): ragged M, residual + ReLU, split-K, and the stride-2 1x1 that must NOT take it
     (2, 19, 21, 256, 192, 1, 1, 2, 0),
     (1, 30, 54, 512, 128, 1, 1, 0, 3),
@@ -61,8 +65,8 @@ CONVS = [
 ]
 
 
-def _is_wino(Cin, Cout, K, s, splitk):
-    return K == 3 and s == 1 and Cin >= 128 and Cin % 32 == 0 and Cout % 64 == 0 and splitk == 0
+def _is_wino(Cin, Cout, K, s, splitk, tiles=0):
+    return K == 3 and s == 1 and (Cin >= 128 or (Cin == 64 and tiles >= 16384)) and Cin % 32 == 0 and Cout % 64 == 0 and splitk == 0
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,K,s,flags,splitk", CONVS)
@@ -83,8 +87,13 @@ def test_conv_matches_fp64_reference(B, H, W, Cin, Cout, K, s, flags, splitk, mo
     # Winograd-eligible shapes run under BOTH GEMM instances (16 waves x 1 position, 8 waves x 2 positions), whatever the
     # default choice for their channel count is
     monkeypatch.setenv("STCN_FUSION_CONV12", "1")          # the 12-channel instance of the FusionNet kernel is off by default
-    for ppw in (("1", "2") if _is_wino(Cin, Cout, K, s, splitk) else (None,)):
-        if ppw:
+    variants = ("1", "2") if _is_wino(Cin, Cout, K, s, splitk, B * ((OH + 1) // 2) * ((OW + 1) // 2)) else (None,)
+    if flags & 4:
+        variants = (None, "chunk")
+    for ppw in variants:
+        if ppw == "chunk":
+            monkeypatch.setenv("STCN_WINO4_CHUNK_MB", "1")
+        elif ppw:
             monkeypatch.setenv("STCN_WINO_PPW", ppw)
         y = torch.empty(B, OH, OW, Cout, device="cuda")
         call("stcn_test_conv", stream(), nhwc(x), dev(w.permute(0, 2, 3, 1)), dev(b),

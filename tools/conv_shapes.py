@@ -67,6 +67,13 @@ def main():
             continue
         if batch:
             B = batch
+        # the layers the engine runs as F(4x4,3x3) (engine.cpp decoder_layer()): hooks.cpp reads the switch per call
+        if name == "custom":
+            pass                                                            # ad-hoc shape: the caller's environment decides
+        elif name.startswith(("dec", "key_comp", "val.fuser")) and "--no-f4" not in sys.argv:
+            os.environ["STCN_BENCH_CONV_F4"] = "1"
+        else:
+            os.environ.pop("STCN_BENCH_CONV_F4", None)
         ms, fl = C.c_float(), C.c_double()
         _lib.check(lib.stcn_bench_conv(s, B, H, W, Cin, Cout, K, K, st, K // 2, splitk, iters, C.byref(ms), C.byref(fl)))
         if sweep:

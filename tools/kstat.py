@@ -8,7 +8,9 @@ import sys
 d = sys.argv[1]
 subs = sys.argv[2:]
 f = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)[0]
-for r in csv.DictReader(open(f)):
+rows = list(csv.DictReader(open(f)))
+print(f"total kernel time {sum(float(r['TotalDurationNs']) for r in rows) / 1e6:.2f} ms ({f})")
+for r in rows:
     n = r["Name"]
     if subs and not any(s in n for s in subs):
         continue
