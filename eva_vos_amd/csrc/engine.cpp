@@ -98,7 +98,8 @@ static int upload(Model &m, const std::vector<float> &h, float **dev) {
 
 int make_wino(Model &m, ConvW &cw, const std::vector<float> &w) {
     static const bool on = [] { const char *e = getenv("STCN_WINOGRAD"); return !e || atoi(e) != 0; }();
-    if (!on || cw.kh != 3 || cw.kw != 3 || cw.cin_p % 32 || cw.cin_p < wino_min_cin() || cw.cout % 64) return STCN_OK;
+    const bool fusion32 = cw.cin_p == 32 && cw.cout == 32;           // FusionNet's 32 -> 32 layers: fusion_wino_kernel (fusion_conv.hip)
+    if (!on || cw.kh != 3 || cw.kw != 3 || cw.cin_p % 32 || ((cw.cin_p < wino_min_cin() || cw.cout % 64) && !fusion32)) return STCN_OK;
     std::vector<float> u((size_t)16 * cw.cin_p * cw.cout);
     wino_transform_weights(w.data(), cw.cout, cw.cin_p, cw.Kp, u.data());
     return upload(m, u, &cw.wino_u);
@@ -373,7 +374,8 @@ int run_conv(const Model &m, Work &w, hipStream_t s, const char *name, const flo
     const bool wino4 = wino4_need > 0 && wino4_need <= w.wino_v_floats;
     const size_t wino_need = force_splitk > 0 || fus || wino4 ? 0 : wino_workspace_floats(p);
     const bool wino = wino_need > 0 && wino_need <= w.wino_v_floats;
-    const double fl_exec = wino4 ? 2.0 * (double)wino4_need * p.N : (wino ? 2.0 * (double)(wino_need / cw.cin_p) * cw.cin_p * p.N : fl);
+    const double fl_exec = wino4 ? 2.0 * (double)wino4_need * p.N : (wino ? 2.0 * (double)(wino_need / cw.cin_p) * cw.cin_p * p.N :
+                           (fus && fusion_conv_winograd(p) ? 2.0 * 16.0 * ((p.H + 3) / 4 * 2) * (double)((p.W + 31) / 32 * 16) * cw.cin_p * p.N : fl));
     hipEvent_t *eg = nullptr, *er = nullptr, *ei = nullptr;
     hipEvent_t *eg4[16] = {}, *ei4[16] = {};                    // per chunk of a chunked F(4x4) launch
     int n4 = 1;

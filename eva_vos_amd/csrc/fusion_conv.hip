@@ -164,6 +164,152 @@ __global__ __launch_bounds__(256, 2) void fusion_conv_kernel(const float *__rest
     }
 }
 
+// ---------------------------------------------------------------------------------------------- 32 -> 32 as Winograd F(2x2,3x3)
+// The direct kernel above runs at 0.8 of the matrix rate the chip holds: the only way down is fewer MFMAs.  F(2x2,3x3) needs 16
+// multiplies per 2x2 outputs instead of 36 (exact-fp32 arithmetic: the transforms add, subtract and halve), and at 32 channels
+// everything fits a workgroup:
+//   * same persistent structure and patches (4 output rows x 32 columns = 2 x 16 tiles = ONE 32-row MFMA block, 6 x 34 input
+//     pixels in LDS, the next patch's global loads in flight under the MFMAs);
+//   * wave xi (of 4) owns the vertical transform index xi: its 4 positions (xi, nu) x 4 k-blocks of U live in 64 registers for
+//     the whole launch; it builds its A fragments straight from the patch - row transform B^T needs just two input rows per xi
+//     (d0 - d2, d1 + d2, d2 - d1, d1 - d3), the column transform four shifted pixels: 8 ds_read_b128 + 32 VALU per k-block, no V
+//     array anywhere - and runs 64 MFMAs per patch (the direct kernel: 144);
+//   * output transform: along nu in registers (u0 = m0 + m1 + m2, u1 = m1 - m2 - m3), along xi through a 32 KB LDS exchange
+//     (the four waves hold the four xi): work item = (tile, output column, 4 channels), 16-byte reads / residual loads / stores.
+template <bool RELU_OUT, bool HAS_RES>
+__global__ __launch_bounds__(256, 2) void fusion_wino_kernel(const float *__restrict__ x, const float *__restrict__ U,
+                                                             const float *__restrict__ bias, const float *__restrict__ res,
+                                                             float *__restrict__ y, int H, int W, int tiles_x, int n_patches) {
+    constexpr int CIN = 32, KB = 4, LP = CIN + 4, PH = 4, PW = 32;
+    constexpr int NPIX = (PH + 2) * (PW + 2), PBUF = NPIX * LP;
+    constexpr int CHP = 8, PPI = 256 / CHP, NIT = (NPIX + PPI - 1) / PPI;
+    extern __shared__ __attribute__((aligned(16))) float patch[];            // [(PH + 2)][(PW + 2)][LP], then the exchange [4 xi][2 j][32 tiles][32 ch]
+    float *ex = patch + PBUF;
+    const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, h = lane >> 5;
+    const int xi = __builtin_amdgcn_readfirstlane(t >> 6);
+
+    f32x4 st[NIT];
+    int p0 = t / CHP;
+    const int part = t % CHP;
+    auto gload = [&](int pidx) {                                              // out-of-image pixels are zero (the conv's padding)
+        const int by = pidx / tiles_x, bx = pidx - by * tiles_x;
+        const int x0 = bx * PW, y0 = by * PH;
+        asm volatile("" : "+v"(p0));                                          // keeps the per-chunk index math inside the loop
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int p = p0 + PPI * i;
+            const int py = p / (PW + 2), px = p - py * (PW + 2);
+            const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (p < NPIX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
+                v = *reinterpret_cast<const f32x4 *>(x + ((long)gy * W + gx) * CIN + 4 * part);
+            st[i] = v;
+        }
+    };
+    auto sstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int p = p0 + PPI * i;
+            if (p < NPIX) *reinterpret_cast<f32x4 *>(patch + p * LP + 4 * part) = st[i];
+        }
+    };
+    int pidx = blockIdx.x;
+    gload(pidx);
+    // ---- this wave's slice of U [16][KB][32][8] -> registers: ur[nu][kb] = U[pos = 4 xi + nu][kb][n = l31][4 h .. 4 h + 3]
+    f32x4 ur[4][KB];
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) ur[nu][kb] = *reinterpret_cast<const f32x4 *>(U + ((((4 * xi + nu) * KB + kb) * 32 + l31) << 3) + 4 * h);
+    sstore();
+    // lane = tile (ty, tx) of the patch; B^T row xi = d[ra] + sb d[rb]: (0, 2, -), (1, 2, +), (2, 1, -), (1, 3, -)
+    const int ty = l31 >> 4, tx = l31 & 15;
+    const int ra = xi == 0 ? 0 : (xi == 2 ? 2 : 1), rb = xi == 0 ? 2 : (xi == 1 ? 2 : (xi == 2 ? 1 : 3));
+    const float sb = xi == 1 ? 1.f : -1.f;
+    const float *pa = patch + ((2 * ty + ra) * (PW + 2) + 2 * tx) * LP + 4 * h;
+    const float *pb = patch + ((2 * ty + rb) * (PW + 2) + 2 * tx) * LP + 4 * h;
+    const int cq = t & 7, tile = (t >> 3) & 31;                               // combine: thread = (tile, 4 channels); column j = pass
+    const int oty = tile >> 4, otx = tile & 15;
+    const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + 4 * cq);
+    for (; pidx < n_patches; pidx += gridDim.x) {
+        __syncthreads();                                                      // the patch is in LDS, the exchange is free
+        const int nxt = pidx + gridDim.x;
+        if (nxt < n_patches) gload(nxt);                                      // lands while the MFMAs below run
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 acc[4];
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[nu][e] = 0.f;
+        f32x4 da[4], db[4], v[4];
+        auto dread = [&](int kb) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                da[c] = *reinterpret_cast<const f32x4 *>(pa + c * LP + 8 * kb);
+                db[c] = *reinterpret_cast<const f32x4 *>(pb + c * LP + 8 * kb);
+            }
+        };
+        auto vmake = [&]() {
+            f32x4 tt[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) tt[c] = da[c] + db[c] * sb;
+            v[0] = tt[0] - tt[2]; v[1] = tt[1] + tt[2]; v[2] = tt[2] - tt[1]; v[3] = tt[1] - tt[3];
+        };
+        dread(0);
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            vmake();
+            if (kb + 1 < KB) dread(kb + 1);                                   // the next k-block's pixels under this one's MFMAs
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int nu = 0; nu < 4; ++nu) acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[nu][j], ur[nu][kb][j], acc[nu], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- residual block of the combine step: requested now, used after the barrier
+        const int by = pidx / tiles_x, bx = pidx - by * tiles_x;
+        const int x0 = bx * PW, y0 = by * PH;
+        const int oy = y0 + 2 * oty, ox = x0 + 2 * otx;
+        long po[2][2];
+        f32x4 rv[2][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                po[j][i] = ((long)min(oy + i, H - 1) * W + min(ox + j, W - 1)) * 32 + 4 * cq;
+                rv[j][i] = HAS_RES ? *reinterpret_cast<const f32x4 *>(res + po[j][i]) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        // ---- output transform along nu, then the exchange: ex[xi][j][tile row of the C layout][channel]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            ex[((xi * 2 + 0) * 32 + row) * 32 + l31] = acc[0][r] + acc[1][r] + acc[2][r];
+            ex[((xi * 2 + 1) * 32 + row) * 32 + l31] = acc[1][r] - acc[2][r] - acc[3][r];
+        }
+        __syncthreads();                                                      // every wave is past its patch reads; the exchange is full
+        if (nxt < n_patches) sstore();
+        const f32x4 *ex4 = reinterpret_cast<const f32x4 *>(ex) + tile * 8 + cq;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const f32x4 e0 = ex4[(0 * 2 + j) * 256], e1 = ex4[(1 * 2 + j) * 256], e2 = ex4[(2 * 2 + j) * 256], e3 = ex4[(3 * 2 + j) * 256];
+            f32x4 o[2] = {e0 + e1 + e2, e1 - e2 - e3};
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                o[i] += bv + rv[j][i];
+                if (RELU_OUT) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) o[i][c] = fmaxf(o[i][c], 0.f);
+                }
+                asm volatile("" : "+v"(o[i]));                                 // pinned in front of the masked stores
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                if (oy + i < H && ox + j < W) *reinterpret_cast<f32x4 *>(y + po[j][i]) = o[i];
+        }
+    }
+}
+
 // conv1 (9 -> 12 channels in HBM, 16 per tap here: a quarter of its MFMAs multiply zeros) measured 53 us on this kernel, 49 us
 // on the generic one: off by default (STCN_FUSION_CONV12=1 switches it on; the instance stays tested)
 static bool fusion_conv12() {
@@ -177,6 +323,13 @@ bool fusion_conv_eligible(const ConvP &p) {
            p.K == 9 * p.Cin && (p.y_bs == 0) && (!p.res || !p.res_bmod) && p.bias;
 }
 
+static bool fusion_wino() {
+    const char *e = getenv("STCN_FUSION_WINO");                              // read per launch: tests run both kernels
+    return !e || atoi(e) != 0;
+}
+
+bool fusion_conv_winograd(const ConvP &p) { return p.Cin == 32 && p.wino_u && fusion_wino(); }
+
 void fusion_conv_launch(const ConvP &p, hipStream_t s, hipEvent_t *ev) {
     constexpr int PH = 4;
     const int tiles_x = (p.W + 31) / 32, tiles_y = (p.H + PH - 1) / PH, n_patches = tiles_x * tiles_y;
@@ -187,6 +340,23 @@ void fusion_conv_launch(const ConvP &p, hipStream_t s, hipEvent_t *ev) {
         return 2 * (cus > 0 ? cus : 256);
     }();
     const dim3 grid((unsigned)(n_patches < resident ? n_patches : resident));
+    if (fusion_conv_winograd(p)) {
+        const size_t ldsw = (size_t)((PH + 2) * 34 * 36 + 4 * 2 * 32 * 32) * sizeof(float);
+#define STCN_FW(RL_, RS_)                                                                                                          \
+    do {                                                                                                                          \
+        auto kfn = fusion_wino_kernel<RL_, RS_>;                                                                                  \
+        if (ev) hipExtLaunchKernelGGL(kfn, grid, dim3(256), ldsw, s, ev[0], ev[1], 0, p.x0, p.wino_u, p.bias, p.res, p.y, p.H, p.W, tiles_x, n_patches); \
+        else hipLaunchKernelGGL(kfn, grid, dim3(256), ldsw, s, p.x0, p.wino_u, p.bias, p.res, p.y, p.H, p.W, tiles_x, n_patches);  \
+    } while (0)
+        switch ((p.relu_out ? 2 : 0) | (p.res ? 1 : 0)) {
+            case 0: STCN_FW(false, false); break;
+            case 1: STCN_FW(false, true); break;
+            case 2: STCN_FW(true, false); break;
+            default: STCN_FW(true, true); break;
+        }
+#undef STCN_FW
+        return;
+    }
     const int cinp = (p.Cin + 7) / 8 * 8;
     const size_t lds = (size_t)2 * (PH + 2) * 34 * (cinp + 4) * sizeof(float);
 #define STCN_FC(CIN_, RL_, RS_)                                                                                                   \

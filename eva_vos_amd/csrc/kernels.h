@@ -92,6 +92,7 @@ void wino4_transform_weights(const float *w, int N, int Cin, int Kp, float *U);
 
 // FusionNet convs (fusion_conv.hip): 3x3, stride 1, Cout = 32, Cin = 32 or 12, one dense image: weights in registers, patch in LDS
 bool fusion_conv_eligible(const ConvP &p);
+bool fusion_conv_winograd(const ConvP &p);      // an eligible conv runs as Winograd F(2x2,3x3) inside the workgroup (32 -> 32 layers)
 void fusion_conv_launch(const ConvP &p, hipStream_t s, hipEvent_t *ev_gemm = nullptr);
 
 // Cout == 1 convolution (decoder.pred, FusionNet.final_conv): one dot product per output pixel.
