@@ -105,6 +105,18 @@ int make_wino(Model &m, ConvW &cw, const std::vector<float> &w) {
     return upload(m, u, &cw.wino_u);
 }
 
+// FusionNet conv1 (12 channels per pixel in HBM, 9 of them live): U over 16 zero-padded channels for fusion_wino_kernel<12>
+int make_wino_fusion12(Model &m, ConvW &cw, const std::vector<float> &w) {
+    static const bool on = [] { const char *e = getenv("STCN_WINOGRAD"); return !e || atoi(e) != 0; }();
+    if (!on || cw.kh != 3 || cw.kw != 3 || cw.cin_p != 12 || cw.cout != 32) return STCN_OK;
+    std::vector<float> w16((size_t)32 * 9 * 16, 0.f), u((size_t)16 * 16 * 32);
+    for (int n = 0; n < 32; ++n)
+        for (int tap = 0; tap < 9; ++tap)
+            for (int c = 0; c < 12; ++c) w16[((size_t)n * 9 + tap) * 16 + c] = w[(size_t)n * cw.Kp + tap * 12 + c];
+    wino_transform_weights(w16.data(), 32, 16, 9 * 16, u.data());
+    return upload(m, u, &cw.wino_u);
+}
+
 int make_wino4(Model &m, ConvW &cw, const std::vector<float> &w) {
     static const bool on = [] { const char *e = getenv("STCN_WINO4"); return !e || atoi(e) != 0; }();
     if (!on || cw.kh != 3 || cw.kw != 3 || cw.cin_p % 32 || cw.cin_p < 128 || cw.cout % 32) return STCN_OK;
@@ -162,7 +174,7 @@ static int add_convs(Model &m, const std::map<std::string, HostT> &sd) {
         if (rc) return rc;
         rc = upload(m, bias, &cw.bias);
         if (rc) return rc;
-        if ((rc = make_wino(m, cw, w))) return rc;
+        if ((rc = make_wino(m, cw, w)) || (rc = make_wino_fusion12(m, cw, w))) return rc;
         if (decoder_layer(pre) && (rc = make_wino4(m, cw, w))) return rc;
         cw.bias0 = bias[0];
         m.conv[pre] = cw;
@@ -375,7 +387,7 @@ int run_conv(const Model &m, Work &w, hipStream_t s, const char *name, const flo
     const size_t wino_need = force_splitk > 0 || fus || wino4 ? 0 : wino_workspace_floats(p);
     const bool wino = wino_need > 0 && wino_need <= w.wino_v_floats;
     const double fl_exec = wino4 ? 2.0 * (double)wino4_need * p.N : (wino ? 2.0 * (double)(wino_need / cw.cin_p) * cw.cin_p * p.N :
-                           (fus && fusion_conv_winograd(p) ? 2.0 * 16.0 * ((p.H + 3) / 4 * 2) * (double)((p.W + 31) / 32 * 16) * cw.cin_p * p.N : fl));
+                           (fus && fusion_conv_winograd(p) ? 2.0 * 16.0 * ((p.H + 3) / 4 * 2) * (double)((p.W + 31) / 32 * 16) * ((cw.cin_p + 7) / 8 * 8) * p.N : fl));
     hipEvent_t *eg = nullptr, *er = nullptr, *ei = nullptr;
     hipEvent_t *eg4[16] = {}, *ei4[16] = {};                    // per chunk of a chunked F(4x4) launch
     int n4 = 1;

@@ -21,6 +21,7 @@ struct ConvW;
 int make_wino(Model &m, ConvW &cw, const std::vector<float> &w_host);
 // F(4x4,3x3) weights of a decoder-side 3x3 conv (no-op when not eligible)
 int make_wino4(Model &m, ConvW &cw, const std::vector<float> &w_host);
+int make_wino_fusion12(Model &m, ConvW &cw, const std::vector<float> &w_host);   // FusionNet conv1: U over 16 zero-padded channels
 #define HIPCHK(x)                                                                          \
     do {                                                                                   \
         hipError_t e_ = (x);                                                               \

@@ -176,13 +176,15 @@ __global__ __launch_bounds__(256, 2) void fusion_conv_kernel(const float *__rest
 //     array anywhere - and runs 64 MFMAs per patch (the direct kernel: 144);
 //   * output transform: along nu in registers (u0 = m0 + m1 + m2, u1 = m1 - m2 - m3), along xi through a 32 KB LDS exchange
 //     (the four waves hold the four xi): work item = (tile, output column, 4 channels), 16-byte reads / residual loads / stores.
-template <bool RELU_OUT, bool HAS_RES>
+// CIN = 12 (conv1: 9 channels padded to 12 in HBM): 16 channels per pixel in LDS (zero filled), two k-blocks, U built from the
+// zero-padded weights.
+template <int CIN, bool RELU_OUT, bool HAS_RES>
 __global__ __launch_bounds__(256, 2) void fusion_wino_kernel(const float *__restrict__ x, const float *__restrict__ U,
                                                              const float *__restrict__ bias, const float *__restrict__ res,
                                                              float *__restrict__ y, int H, int W, int tiles_x, int n_patches) {
-    constexpr int CIN = 32, KB = 4, LP = CIN + 4, PH = 4, PW = 32;
+    constexpr int CINP = (CIN + 7) / 8 * 8, KB = CINP / 8, LP = CINP + 4, PH = 4, PW = 32;
     constexpr int NPIX = (PH + 2) * (PW + 2), PBUF = NPIX * LP;
-    constexpr int CHP = 8, PPI = 256 / CHP, NIT = (NPIX + PPI - 1) / PPI;
+    constexpr int CH = CIN / 4, CHP = CH > 4 ? 8 : 4, PPI = 256 / CHP, NIT = (NPIX + PPI - 1) / PPI;
     extern __shared__ __attribute__((aligned(16))) float patch[];            // [(PH + 2)][(PW + 2)][LP], then the exchange [4 xi][2 j][32 tiles][32 ch]
     float *ex = patch + PBUF;
     const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, h = lane >> 5;
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void fusion_wino_kernel(const float *__rest
             const int py = p / (PW + 2), px = p - py * (PW + 2);
             const int gy = y0 - 1 + py, gx = x0 - 1 + px;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (p < NPIX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
+            if (p < NPIX && part < CH && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
                 v = *reinterpret_cast<const f32x4 *>(x + ((long)gy * W + gx) * CIN + 4 * part);
             st[i] = v;
         }
@@ -210,11 +212,14 @@ __global__ __launch_bounds__(256, 2) void fusion_wino_kernel(const float *__rest
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
             const int p = p0 + PPI * i;
-            if (p < NPIX) *reinterpret_cast<f32x4 *>(patch + p * LP + 4 * part) = st[i];
+            if (p < NPIX && part < CH) *reinterpret_cast<f32x4 *>(patch + p * LP + 4 * part) = st[i];
         }
     };
     int pidx = blockIdx.x;
     gload(pidx);
+    if (CINP != CIN) {                                                        // the zero channels CIN .. CINP - 1 of every pixel (once)
+        for (int p = t; p < NPIX; p += 256) *reinterpret_cast<f32x4 *>(patch + p * LP + CIN) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     // ---- this wave's slice of U [16][KB][32][8] -> registers: ur[nu][kb] = U[pos = 4 xi + nu][kb][n = l31][4 h .. 4 h + 3]
     f32x4 ur[4][KB];
 #pragma unroll
@@ -317,18 +322,19 @@ static bool fusion_conv12() {
     return e && atoi(e) != 0;
 }
 
-bool fusion_conv_eligible(const ConvP &p) {
-    static const bool on = [] { const char *e = getenv("STCN_FUSION_CONV"); return !e || atoi(e) != 0; }();
-    return on && p.N == 32 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.B == 1 && !p.x1 && !p.relu_in && (p.Cin == 32 || (p.Cin == 12 && fusion_conv12())) &&
-           p.K == 9 * p.Cin && (p.y_bs == 0) && (!p.res || !p.res_bmod) && p.bias;
-}
-
 static bool fusion_wino() {
     const char *e = getenv("STCN_FUSION_WINO");                              // read per launch: tests run both kernels
     return !e || atoi(e) != 0;
 }
 
-bool fusion_conv_winograd(const ConvP &p) { return p.Cin == 32 && p.wino_u && fusion_wino(); }
+bool fusion_conv_winograd(const ConvP &p) { return (p.Cin == 32 || p.Cin == 12) && p.wino_u && fusion_wino(); }
+
+bool fusion_conv_eligible(const ConvP &p) {
+    static const bool on = [] { const char *e = getenv("STCN_FUSION_CONV"); return !e || atoi(e) != 0; }();
+    return on && p.N == 32 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.B == 1 && !p.x1 && !p.relu_in &&
+           (p.Cin == 32 || (p.Cin == 12 && (fusion_conv12() || fusion_conv_winograd(p)))) &&
+           p.K == 9 * p.Cin && (p.y_bs == 0) && (!p.res || !p.res_bmod) && p.bias;
+}
 
 void fusion_conv_launch(const ConvP &p, hipStream_t s, hipEvent_t *ev) {
     constexpr int PH = 4;
@@ -341,10 +347,14 @@ void fusion_conv_launch(const ConvP &p, hipStream_t s, hipEvent_t *ev) {
     }();
     const dim3 grid((unsigned)(n_patches < resident ? n_patches : resident));
     if (fusion_conv_winograd(p)) {
-        const size_t ldsw = (size_t)((PH + 2) * 34 * 36 + 4 * 2 * 32 * 32) * sizeof(float);
+        const size_t ldsw = (size_t)((PH + 2) * 34 * ((p.Cin + 7) / 8 * 8 + 4) + 4 * 2 * 32 * 32) * sizeof(float);
 #define STCN_FW(RL_, RS_)                                                                                                          \
     do {                                                                                                                          \
-        auto kfn = fusion_wino_kernel<RL_, RS_>;                                                                                  \
+        if (p.Cin == 12) STCN_FW2(12, RL_, RS_); else STCN_FW2(32, RL_, RS_);                                                     \
+    } while (0)
+#define STCN_FW2(CIN_, RL_, RS_)                                                                                                   \
+    do {                                                                                                                          \
+        auto kfn = fusion_wino_kernel<CIN_, RL_, RS_>;                                                                            \
         if (ev) hipExtLaunchKernelGGL(kfn, grid, dim3(256), ldsw, s, ev[0], ev[1], 0, p.x0, p.wino_u, p.bias, p.res, p.y, p.H, p.W, tiles_x, n_patches); \
         else hipLaunchKernelGGL(kfn, grid, dim3(256), ldsw, s, p.x0, p.wino_u, p.bias, p.res, p.y, p.H, p.W, tiles_x, n_patches);  \
     } while (0)
@@ -355,6 +365,7 @@ void fusion_conv_launch(const ConvP &p, hipStream_t s, hipEvent_t *ev) {
             default: STCN_FW(true, true); break;
         }
 #undef STCN_FW
+#undef STCN_FW2
         return;
     }
     const int cinp = (p.Cin + 7) / 8 * 8;

@@ -48,6 +48,7 @@ int stcn_test_conv(void *stream, const float *x, const float *wgt, const float *
         std::vector<float> hw((size_t)Cout * cw.Kp);
         HIPCHK(hipMemcpy(hw.data(), wpad.p, hw.size() * 4, hipMemcpyDeviceToHost));
         RC(make_wino(m, cw, hw));
+        RC(make_wino_fusion12(m, cw, hw));
         if (flags & 4) { RC(make_wino4(m, cw, hw)); m.wino4_min_wg = 0; }        // flags bit 2: as a decoder layer (F(4x4,3x3))
         w.wino_v_floats = (size_t)16 * Cin * (((size_t)B * ((OH + 1) / 2) * ((OW + 1) / 2) + 63) / 64 * 64);
         RC(wv.alloc(w.wino_v_floats));
@@ -99,6 +100,7 @@ int stcn_bench_conv(void *stream, int B, int H, int W, int Cin, int Cout, int KH
     DevBuf wv;
     if (KH == 3 && stride == 1) {
         RC(make_wino(m, cw, h));
+        RC(make_wino_fusion12(m, cw, h));
         if (getenv("STCN_BENCH_CONV_F4")) RC(make_wino4(m, cw, h));              // time the layer as a decoder layer
         w.wino_v_floats = (size_t)16 * Cin * (((size_t)B * ((OH + 1) / 2) * ((OW + 1) / 2) + 63) / 64 * 64);
         RC(wv.alloc(w.wino_v_floats));

@@ -90,7 +90,7 @@ def test_conv_matches_fp64_reference(B, H, W, Cin, Cout, K, s, flags, splitk, mo
     variants = ("1", "2") if _is_wino(Cin, Cout, K, s, splitk, B * ((OH + 1) // 2) * ((OW + 1) // 2)) else (None,)
     if flags & 4:
         variants = (None, "chunk")
-    if Cin == 32 and Cout == 32 and K == 3:
+    if Cin in (12, 32) and Cout == 32 and K == 3:
         variants = (None, "direct")           # FusionNet layers: the in-workgroup Winograd kernel (default) and the direct one
     for ppw in variants:
         if ppw == "chunk":
