@@ -302,8 +302,8 @@ static bool wino_enabled() {
 
 // fewest input channels worth the transforms (STCN_WINO_MIN_CIN)
 int wino_min_cin() {
-    static const int v = [] { const char *e = getenv("STCN_WINO_MIN_CIN"); return e ? atoi(e) : 64; }();
-    return v;
+    const char *e = getenv("STCN_WINO_MIN_CIN");          // read per call: the unit tests run the 64-channel path
+    return e ? atoi(e) : 128;
 }
 
 // floats of V workspace the Winograd path needs for this conv (0: not eligible)
@@ -312,8 +312,9 @@ size_t wino_workspace_floats(const ConvP &p) {
     if (p.Cin % 32 || p.Cin < wino_min_cin() || p.N % WN || p.bs0 == 0) return 0;
     const long Mt = (long)p.B * ((p.OH + 1) / 2) * ((p.OW + 1) / 2);
     const long Mt_pad = (Mt + WT - 1) / WT * WT;
-    // 64-channel layers (K = 8 k-blocks): the transforms and the epilogue outweigh the MFMA saving unless the launch is large -
-    // 64 -> 64 at 120x216: 94 -> 76 us over a 5-frame group (32400 tiles), 26 -> 32 us for one frame (6480 tiles)
+    // 64-channel layers (K = 8 k-blocks; opt-in: STCN_WINO_MIN_CIN=64): the transforms and the epilogue outweigh the MFMA saving
+    // unless the launch is large - 64 -> 64 at 120x216 over a 5-frame group (32400 tiles): 94 -> 76 us back to back, but 81 -> 78 us
+    // inside the engine's launch sequence (rocprofv3 trace): not worth 133 MB of V per layer; one frame (6480 tiles): 26 -> 32 us
     if (p.Cin < 128 && Mt < 16384) return 0;
     if (16L * p.Cin * Mt_pad * 4 >= (1L << 32)) return 0;                  // 32-bit buffer offsets
     if ((long)p.B * (p.y_bs ? p.y_bs : (long)p.OH * p.OW * p.N) * 4 >= (1L << 32)) return 0;

@@ -86,6 +86,7 @@ def test_conv_matches_fp64_reference(B, H, W, Cin, Cout, K, s, flags, splitk, mo
         ref = F.relu(ref)
     # Winograd-eligible shapes run under BOTH GEMM instances (16 waves x 1 position, 8 waves x 2 positions), whatever the
     # default choice for their channel count is
+    monkeypatch.setenv("STCN_WINO_MIN_CIN", "64")          # the opt-in F(2x2) path of 64-channel layers stays tested
     monkeypatch.setenv("STCN_FUSION_CONV12", "1")          # the 12-channel instance of the FusionNet kernel is off by default
     variants = ("1", "2") if _is_wino(Cin, Cout, K, s, splitk, B * ((OH + 1) // 2) * ((OW + 1) // 2)) else (None,)
     if flags & 4:
