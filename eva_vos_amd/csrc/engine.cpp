@@ -382,7 +382,8 @@ int run_conv(const Model &m, Work &w, hipStream_t s, const char *name, const flo
     const double fl = 2.0 * p.M * p.N * (double)(cw.kh * cw.kw * cw.cin);
     // stride-1 3x3 convs run as Winograd F(2x2,3x3) (2.25x fewer MFMA FLOP, exact-fp32 arithmetic) unless a split-K is forced
     // decoder-side layers with enough tiles: F(4x4,3x3) (4x fewer MFMA FLOP); else F(2x2,3x3) (2.25x fewer)
-    const size_t wino4_need = force_splitk > 0 || fus ? 0 : wino4_workspace_floats(p, m.wino4_min_wg);
+    static const int min_wg_env = [] { const char *e = getenv("STCN_WINO4_MIN_WG"); return e ? atoi(e) : -1; }();
+    const size_t wino4_need = force_splitk > 0 || fus ? 0 : wino4_workspace_floats(p, min_wg_env >= 0 && m.wino4_min_wg ? min_wg_env : m.wino4_min_wg);
     const bool wino4 = wino4_need > 0 && wino4_need <= w.wino_v_floats;
     const size_t wino_need = force_splitk > 0 || fus || wino4 ? 0 : wino_workspace_floats(p);
     const bool wino = wino_need > 0 && wino_need <= w.wino_v_floats;

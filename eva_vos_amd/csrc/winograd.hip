@@ -328,8 +328,9 @@ int wino_plan_splitk(const ConvP &p, size_t slab_floats) {
     const int TH = (p.OH + 1) / 2, TW = (p.OW + 1) / 2;
     const int Mt_pad = (p.B * TH * TW + WT - 1) / WT * WT, KB = p.Cin / 8;
     const int ntile = (Mt_pad / WT) * (p.N / WN);
+    static const int split_below = [] { const char *e = getenv("STCN_WINO_SPLIT_BELOW"); return e ? atoi(e) : 160; }();
     int sk = 1;
-    if (ntile < 160) {
+    if (ntile < split_below) {
         sk = (256 + ntile - 1) / ntile;
         const int smax = KB / 8 < 1 ? 1 : KB / 8;        // at least 8 k-blocks per piece
         sk = sk > smax ? smax : sk;
