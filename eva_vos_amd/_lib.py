@@ -12,7 +12,8 @@ import torch  # noqa: F401  (first: PyTorch-ROCm bundles its own libamdhip64/lib
 #               before libstcn_hip.so makes the process use ONE HIP runtime, whatever the import order)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libstcn_hip.so")
+# STCN_LIB: another build of the same library (measurement aid: tools/gpu_ab_trace.sh compares two builds on one GPU box)
+LIB_PATH = os.environ.get("STCN_LIB") or os.path.join(_HERE, "libstcn_hip.so")
 
 K_CLASSES = ("conv", "conv_reduce", "memread", "elementwise", "conv_n1", "other", "wino_input", "fusion_conv", "attention")
 
