@@ -711,6 +711,20 @@ def main():
                                "algorithmic_frac_of_peak": alg / FP32_MFMA_PEAK_TFLOPS,
                                "executed_over_algorithmic_flop": conv["exec_flops"] / conv["flops"] if conv["flops"] > 0 else 0.0,
                                "wino_input_transform_ms_share_of_conv": wi["ms"] / conv_all_ms if conv_all_ms > 0 else 0.0}
+            # what the matrix pipes deliver on this chip under a pure fp32-MFMA load (register operands, ~30 ms): the datasheet peak
+            # assumes 2.4 GHz, the chip holds ~2.0 GHz under matrix load
+            try:
+                import ctypes as C
+                from eva_vos_amd import _lib
+                tf, ms_ = C.c_float(), C.c_float()
+                _lib.check(_lib.lib().stcn_bench_mfma_rate(C.c_void_p(torch.cuda.current_stream().cuda_stream), 30, C.byref(tf), C.byref(ms_)))
+                out["roofline"]["sustained_mfma_tflops_measured"] = tf.value
+                out["roofline"]["frac_of_sustained_mfma_rate"] = ach / tf.value if tf.value > 0 else None
+                out["roofline"]["sustained_what"] = (f"mfma_probe_kernel: v_mfma_f32_32x32x2_f32 on register operands, no memory traffic, {ms_.value:.1f} ms on all CUs "
+                                                     f"= {tf.value / FP32_MFMA_PEAK_TFLOPS * 2.4:.2f} GHz-equivalent of the {FP32_MFMA_PEAK_TFLOPS} TFLOP/s @ 2.4 GHz datasheet peak")
+            except Exception as ex:                              # the probe is an extra: never fail the line for it
+                out["roofline"]["sustained_mfma_tflops_measured"] = None
+                out["roofline"]["sustained_what"] = f"probe failed: {ex}"
             hb = prof.pop("conv_hbm_bound")                      # subset of "conv": launches below 19.7 FLOP/B
             if conv["flops"] > 0:
                 out["roofline"]["winograd_f2x2_share_of_algorithmic_flop"] = hb.get("wino2_flops", 0.0) / conv["flops"]

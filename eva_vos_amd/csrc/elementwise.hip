@@ -436,4 +436,50 @@ void cbam_launch(const float *x, float *out, int B, int h, int w, const CbamW &c
                        out);
 }
 
+// ------------------------------------------------------------------------------------------------ matrix-rate probe
+// What do the matrix pipes deliver under a pure fp32-MFMA load on THIS chip right now?  12 waves per CU-resident workgroup (3 per
+// SIMD, as the F(4x4) GEMM), each wave `iters` x 12 v_mfma_f32_32x32x2_f32 on three accumulator chains with non-zero operands in
+// registers: no memory traffic, no LDS.  bench.py reports its rate next to the datasheet peak (the clock the chip holds under
+// matrix load is ~2.0 GHz, not the 2.4 GHz of the datasheet figure).
+typedef float f32x16p __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(768) void mfma_probe_kernel(float *out, int iters, float seed) {
+    f32x16p acc[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[c][e] = 0.f;
+    // 12 operand pairs per lane with pseudo-random mantissas (all-equal or zero operands toggle fewer wires and raise the clock:
+    // cdna_hip_programming.md rule 25); their signs flip every iteration so the sums stay bounded
+    float a[12], b[12];
+    unsigned st = (blockIdx.x * 768u + threadIdx.x) * 2654435761u + 12345u;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+        st = st * 1664525u + 1013904223u; a[j] = seed + (float)((st >> 8) & 0xffff) / 65536.f;
+        st = st * 1664525u + 1013904223u; b[j] = (float)((st >> 8) & 0xffff) / 32768.f - 1.f;
+    }
+    for (int i = 0; i < iters; i += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)                                           // 48 MFMAs (3072 cycles) per 12 sign flips: VALU share < 2 %
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[(3 * j + c + 5 * u) % 12], b[(3 * j + c + 7 * u) % 12], acc[c], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 12; ++j) a[j] = -a[j];
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sum += acc[c][e];
+    if (sum == 123456.789f) out[0] = sum;                                     // keeps the chains alive
+}
+
+// FLOP of one launch = grid x 12 waves x iters x 12 MFMAs x 4096
+double mfma_probe_launch(float *out, int grid, int iters, hipStream_t s) {
+    hipLaunchKernelGGL(mfma_probe_kernel, dim3(grid), dim3(768), 0, s, out, iters, 0.5f);
+    return (double)grid * 12.0 * iters * 12.0 * 4096.0;
+}
+
 }  // namespace stcn

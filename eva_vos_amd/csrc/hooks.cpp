@@ -290,4 +290,30 @@ int stcn_metrics_jf_counts(void *stream, const uint8_t *gt_dev, const uint8_t *p
     return STCN_OK;
 }
 
+int stcn_bench_mfma_rate(void *stream, int ms_target, float *tflops, float *ms_out) {
+    if (!tflops || ms_target < 1 || ms_target > 2000) { set_error("stcn_bench_mfma_rate: bad arguments"); return STCN_E_INVALID; }
+    hipStream_t s = (hipStream_t)stream;
+    int dev = 0, cus = 256;
+    HIPCHK(hipGetDevice(&dev));
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    DevBuf out;
+    RC(out.alloc(64));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    // one wave-iteration = 12 MFMAs x 64 cycles x 3 waves per SIMD: ~1.15 us at 2 GHz; warm-up launch, then the timed one
+    const int iters = ((int)(ms_target * 1000.0 / 1.15) + 3) / 4 * 4;         // the kernel walks 4 iterations per loop trip
+    (void)mfma_probe_launch(out.p, 2 * cus, (iters / 8 + 3) / 4 * 4, s);
+    HIPCHK(hipEventRecord(e0, s));
+    const double fl = mfma_probe_launch(out.p, 2 * cus, iters, s);              // two workgroups per CU in turn (one resident: 768 threads x 2 fit)
+    HIPCHK(hipEventRecord(e1, s));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    HIPCHK(hipGetLastError());
+    *tflops = (float)(fl / (ms * 1e-3) / 1e12);
+    if (ms_out) *ms_out = ms;
+    return STCN_OK;
+}
+
 }  // extern "C"

@@ -176,4 +176,7 @@ void jf_counts_launch(const uint8_t *gt, const uint8_t *pred, int T, int H, int 
 void merge_only_launch(const float *cand_v, const int32_t *cand_i, int NC, int Q, const float *mv, long mv_os, int k,
                        float *readout, long ro_os, hipStream_t s);
 
+// pure fp32-MFMA load (no memory traffic): launches `grid` workgroups of 12 waves x iters x 12 MFMAs, returns the FLOP of the launch
+double mfma_probe_launch(float *out, int grid, int iters, hipStream_t s);
+
 }  // namespace stcn

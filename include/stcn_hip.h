@@ -170,6 +170,11 @@ int stcn_test_fail_at(int n);
 int stcn_bench_conv(void *stream, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
                     int pad, int splitk, int iters, float *avg_ms, double *flops_per_launch);
 
+/* Matrix rate the chip sustains under a pure fp32-MFMA load (v_mfma_f32_32x32x2_f32 on register operands, no memory
+ * traffic) for about ms_target milliseconds: TFLOP/s.  bench.py reports it beside the datasheet peak (the clock under
+ * matrix load is lower than the datasheet's). */
+int stcn_bench_mfma_rate(void *stream, int ms_target, float *tflops, float *ms_out);
+
 /* Per-kernel-class time of the last interact() measured with HIP events on the engine stream
  * (enabled by stcn_engine_set_profiling(e,1); adds a few % overhead).  ms[] indexed by STCN_K_*. */
 enum { STCN_K_CONV = 0, STCN_K_CONV_REDUCE, STCN_K_MEMREAD, STCN_K_ELEMWISE, STCN_K_CONV_N1,
