@@ -132,6 +132,9 @@ struct Wino4G {
     int full_wg, pieces, kb_per_piece;
     float *partial;
     int tm0;                                   // first tile block of this launch (chunked launches, MB = 2)
+    // 2-D blocks per XCD (whole-tile workgroups): an XCD's contiguous range of xb_m x xb_n workgroups covers xb_m tile blocks x xb_n
+    // channel blocks instead of a strip of rows - xb_m + xb_n operand streams through its L2 instead of rows + tiles_n (0: strips)
+    int xb_m, xb_n, xb_cols;
 };
 
 // MB = 32-tile blocks per workgroup.  MB = 1: three fragment sets, loads two k-blocks ahead.  MB = 2 (64 tiles x 32 channels: 25 %
@@ -156,7 +159,14 @@ __global__ __launch_bounds__(64 * W4W) void wino4_gemm_kernel(const Wino4G p, co
     } else {
         swz = xcd_contiguous(blockIdx.x, MB == 1 && p.pieces > 1 ? p.full_wg : (int)gridDim.x);
     }
-    const int tm_l = fastdiv(swz, p.fd_tiles_n), tn = swz - tm_l * tiles_n, tm = tm_l + p.tm0;
+    int tm_l = fastdiv(swz, p.fd_tiles_n), tn = swz - tm_l * tiles_n;
+    if (p.xb_m > 0 && piece < 0) {                                            // swz = block * (xb_m xb_n) + row-major position inside the block
+        const int per = p.xb_m * p.xb_n, blk = swz / per, in = swz - blk * per;
+        const int bm_i = blk / p.xb_cols, bn_i = blk - bm_i * p.xb_cols, im = in / p.xb_n;
+        tm_l = bm_i * p.xb_m + im;
+        tn = bn_i * p.xb_n + (in - im * p.xb_n);
+    }
+    const int tm = tm_l + p.tm0;
     const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);                  // wave-uniform: the position offsets below stay in SGPRs
     const int pos0 = PPW * wave;
@@ -520,6 +530,22 @@ void wino4_launch(const ConvP &p, float *V, size_t slab_floats, hipStream_t s, h
     const int tiles_n = pl.tiles_n, mb = pl.mb, tiles_m = pl.tiles_m;
     g.fd_tpi = fastdiv_make((unsigned)(TH * TW)); g.fd_tw = fastdiv_make((unsigned)TW); g.fd_tiles_n = fastdiv_make((unsigned)tiles_n);
     g.full_wg = pl.full_wg; g.pieces = pl.pieces; g.kb_per_piece = pl.per; g.partial = p.partial;
+    g.xb_m = g.xb_n = g.xb_cols = 0;
+    {   // 2-D XCD blocks for the whole-tile workgroups of an unchunked launch: 8 equal blocks that tile the (rows x tiles_n) grid
+        static const bool xb_on = [] { const char *e = getenv("STCN_WINO4_XCD2D"); return !e || atoi(e) != 0; }();
+        const int rows = pl.full_wg / tiles_n;                                // whole rows of workgroups in the unsplit part
+        if (xb_on && pl.chunks == 1 && pl.full_wg % 8 == 0 && rows * tiles_n == pl.full_wg && tiles_n >= 8) {
+            const int per = pl.full_wg / 8;
+            int best = 0, best_sum = per % tiles_n == 0 ? per / tiles_n + tiles_n : rows + tiles_n;      // strips: rows per XCD + tiles_n streams
+            for (int bn = 2; bn <= tiles_n; ++bn) {
+                if (per % bn || tiles_n % bn) continue;
+                const int bm = per / bn;
+                if (bm < 1 || rows % bm || (rows / bm) * (tiles_n / bn) != 8) continue;
+                if (bm + bn < best_sum) { best_sum = bm + bn; best = bn; }
+            }
+            if (best && best != tiles_n) { g.xb_n = best; g.xb_m = per / best; g.xb_cols = tiles_n / best; }
+        }
+    }
     const size_t lds = (size_t)36 * W4T * W4N * sizeof(float);
     for (int c = 0; c < pl.chunks; ++c) {
         const int tm_lo = c * pl.tm_per_chunk, tm_hi = tm_lo + pl.tm_per_chunk < tiles_m ? tm_lo + pl.tm_per_chunk : tiles_m;
