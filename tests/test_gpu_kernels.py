@@ -108,6 +108,55 @@ def test_conv_matches_fp64_reference(B, H, W, Cin, Cout, K, s, flags, splitk, mo
         assert err < 2e-5, (err, ppw)          # fp32 accumulation vs fp64
 
 
+def _random_conv_cases():
+    """Seeded sweep over the shapes the fixed list cannot enumerate: every Winograd / FusionNet / direct instance under random
+    sizes (ragged tile rows and columns, padded workgroup tiles), batch, residual and ReLU combinations."""
+    rng = np.random.RandomState(20260303)
+    cases = []
+    for i in range(36):
+        kind = ("f2", "f4", "fusion", "direct1x1", "direct3x3s2", "f4")[i % 6]
+        B = int(rng.randint(1, 4))
+        H, W = int(rng.randint(3, 41)), int(rng.randint(3, 49))
+        flags = int(rng.randint(0, 4))                      # bit 0: ReLU on the input, bit 1: ReLU on the output
+        res = bool(rng.randint(0, 2))
+        if kind == "f2":
+            Cin, Cout, K, s = int(rng.choice([128, 160, 256])), int(rng.choice([64, 128, 192])), 3, 1
+        elif kind == "f4":
+            Cin, Cout, K, s = int(rng.choice([128, 256, 288])), int(rng.choice([32, 64, 96, 160])), 3, 1
+            flags |= 4
+        elif kind == "fusion":
+            Cin, Cout, K, s, B = int(rng.choice([12, 32])), 32, 3, 1, 1
+            flags &= 2                                      # the FusionNet kernels take no ReLU on the input
+        elif kind == "direct1x1":
+            Cin, Cout, K, s = int(rng.choice([64, 96, 256])), int(rng.choice([32, 64, 160, 256])), 1, 1
+        else:
+            Cin, Cout, K, s = int(rng.choice([64, 128])), int(rng.choice([64, 128])), 3, 2
+        cases.append((B, H, W, Cin, Cout, K, s, flags, res))
+    return cases
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,K,s,flags,use_res", _random_conv_cases())
+def test_conv_random_shapes_match_fp64_reference(B, H, W, Cin, Cout, K, s, flags, use_res):
+    g = torch.Generator().manual_seed(B * 1000003 + H * 10007 + W * 101 + Cin + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, K, K, generator=g) * (2.0 / (Cin * K * K)) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    OH, OW = (H + 2 * (K // 2) - K) // s + 1, (W + 2 * (K // 2) - K) // s + 1
+    res = torch.randn(B, Cout, OH, OW, generator=g) if use_res else None
+    ref = F.conv2d((F.relu(x) if flags & 1 else x).double(), w.double(), b.double(), stride=s, padding=K // 2)
+    if res is not None:
+        ref = ref + res.double()
+    if flags & 2:
+        ref = F.relu(ref)
+    y = torch.full((B, OH, OW, Cout), float("nan"), device="cuda")     # every output must be written
+    call("stcn_test_conv", stream(), nhwc(x), dev(w.permute(0, 2, 3, 1)), dev(b),
+         None if res is None else nhwc(res), y, B, H, W, Cin, Cout, K, K, s, K // 2, flags, 0)
+    got = y.permute(0, 3, 1, 2).cpu().double()
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 2e-5, err
+
+
 def _memread(mk, mv, qk):
     N, Q, k = mk.shape[0], qk.shape[0], mv.shape[0]
     idx = torch.empty(Q, 50, dtype=torch.int32, device="cuda")
