@@ -380,3 +380,13 @@ def test_engines_on_two_streams_do_not_perturb_each_other(nets):
         for i in range(2):
             assert np.array_equal(got[i][0], solo[i][0]) and np.array_equal(got[i][1], solo[i][1]), (rep, i)
             assert torch.equal(got[i][2], solo[i][2]), (rep, i)
+
+
+def test_mfma_probe_reports_a_plausible_matrix_rate():
+    """stcn_bench_mfma_rate (bench.py's live yardstick beside the datasheet peak): register-operand fp32 MFMAs on all CUs.  The rate
+    must lie between half the datasheet peak and the peak itself (157.3 TFLOP/s at 2.4 GHz; the chip holds ~2.3 GHz on this load)."""
+    import ctypes as C
+    tf, ms = C.c_float(), C.c_float()
+    call("stcn_bench_mfma_rate", stream(), 10, C.byref(tf), C.byref(ms))
+    assert 157.3 / 2 < tf.value <= 157.3 * 1.01, tf.value
+    assert 3.0 < ms.value < 60.0, ms.value
