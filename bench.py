@@ -306,9 +306,18 @@ def r2_roofline(prop, fuse, img, mask0, mask_mid, T, mem_freq, scribble):
     FusionNet + attention read on the frames between the two interacted frames (inference_core.py:184-207).  One video, one
     stream, HIP events per launch (same method as `roofline`)."""
     from mivos.inference_core import InferenceCore
+    res = {}
+    # the shipped mode first (side stream on: FusionNet of a decoded group runs beside the next group), then one stream only
+    e = InferenceCore(prop, fuse, img, 1 if not scribble else mask0.shape[0] - 1, mem_freq=mem_freq)
+    e.interact(mask0, 0, scribble=scribble)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    e.interact(mask_mid, T // 2, scribble=scribble)
+    torch.cuda.synchronize()
+    res["frames_per_s_one_video"] = e.stats()["frames"] / (time.perf_counter() - t0)
+    del e
     la_saved = os.environ.get("STCN_LOOKAHEAD")
     os.environ["STCN_LOOKAHEAD"] = "0"
-    res = {}
     for prof_on in (False, True):
         e = InferenceCore(prop, fuse, img, 1 if not scribble else mask0.shape[0] - 1, mem_freq=mem_freq)
         e.interact(mask0, 0, scribble=scribble)

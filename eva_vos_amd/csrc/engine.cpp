@@ -306,6 +306,7 @@ int Work::init(int nh, int nw, int k_, int key_batch, int group) {
     if ((rc = alloc((void **)&logit4, (size_t)kg * d.hw4 * sizeof(float)))) return rc;
     if ((rc = alloc((void **)&flogit, (size_t)k * d.npix * sizeof(float)))) return rc;
     if ((rc = alloc((void **)&agg, (size_t)(k + 1) * group * d.npix * sizeof(float)))) return rc;
+    if ((rc = alloc((void **)&agg_alt, (size_t)(k + 1) * group * d.npix * sizeof(float)))) return rc;
     if ((rc = alloc((void **)&pooled, (size_t)20 * d.hw16 * sizeof(float)))) return rc;        // [hw16][channels padded to 4 / 8 / 12 / 20]
     if ((rc = alloc((void **)&amap, (size_t)(k + 1) * 2 * d.hw16 * sizeof(float)))) return rc;
     if ((rc = alloc((void **)&attn, (size_t)(k + 1) * 2 * d.npix * sizeof(float)))) return rc;
@@ -777,8 +778,14 @@ static int engine_alloc_common(stcn_engine *e) {
     // next frames then runs on a side stream concurrently with the memory-read / decoder chain.
     if (e->lookahead > 0) {
         HIPCHK(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
-        RC(e->work_side.init(d.nh, d.nw, 1, e->key_batch));
+        RC(e->work_side.init(d.nh, d.nw, e->k, e->key_batch));          // k objects: it also runs FusionNet (fuse_side)
         e->work_side.prof = &e->prof;
+        const char *fs = getenv("STCN_FUSE_SIDE");
+        e->fuse_side = !fs || atoi(fs) != 0;
+        for (int b = 0; b < 2 && e->fuse_side; ++b) {
+            HIPCHK(hipEventCreateWithFlags(&e->ev_dec[b], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&e->ev_fuse[b], hipEventDisableTiming));
+        }
         e->key_ready.assign(e->T, nullptr);
         for (int t = 0; t < e->T; ++t) HIPCHK(hipEventCreateWithFlags(&e->key_ready[t], hipEventDisableTiming));
     }
@@ -834,6 +841,7 @@ int stcn_engine_reset(stcn_engine *e) {
     std::fill(e->slot_of.begin(), e->slot_of.end(), -1);
     std::fill(e->vparts_ready.begin(), e->vparts_ready.end(), 0);
     std::fill(e->key_pending.begin(), e->key_pending.end(), 0);
+    e->fuse_pending[0] = e->fuse_pending[1] = 0;              // both streams were drained above
     e->stats = stcn_stats{};
     return engine_init_outputs(e);
 }
@@ -843,6 +851,7 @@ int stcn_engine_destroy(stcn_engine *e) {
     if (e->stream) (void)hipStreamSynchronize(e->stream); else (void)hipDeviceSynchronize();
     if (e->side) { (void)hipStreamSynchronize(e->side); (void)hipStreamDestroy(e->side); }
     for (hipEvent_t ev : e->key_ready) if (ev) (void)hipEventDestroy(ev);
+    for (int b = 0; b < 2; ++b) { if (e->ev_dec[b]) (void)hipEventDestroy(e->ev_dec[b]); if (e->ev_fuse[b]) (void)hipEventDestroy(e->ev_fuse[b]); }
     e->work_side.release();
     for (void *p : e->allocs) (void)hipFree(p);
     if (e->bank_k) { (void)hipFree(e->bank_k); (void)hipFree(e->bank_msq); (void)hipFree(e->bank_v); }
@@ -1024,6 +1033,11 @@ static int do_pass(stcn_engine *e, int idx, bool forward) {
     const long prs = (long)T * d.npix;                      // prob row stride
     const long agg_fs = (long)(k + 1) * d.npix;             // floats per frame in w.agg
     Work &w = e->work;
+    // FusionNet on the side stream (fuse_side): the fused frames of a decoded group are handed to the side stream, which reads the
+    // group's agg buffer while the main stream goes on with the value encoder and the next group (second agg buffer); in rounds
+    // >= 2 every key is cached, so the side stream has nothing else to do.  Order: ev_dec (main: the group is decoded) -> side
+    // fuses -> ev_fuse (side) -> awaited by the main stream before it overwrites that buffer two groups later / before argmax.
+    const bool offload = fuse && e->fuse_side && e->side;
     int ti = idx + step;
     while (ti != closest) {
         // ---- the group: ti and the following frames up to and including the next bank insertion
@@ -1060,7 +1074,13 @@ static int do_pass(stcn_engine *e, int idx, bool forward) {
                                (long)d.hw16 * 512, nullptr, nullptr, MemReadScratch{w.cand_v, w.cand_i, w.cand_n, w.gmax, w.tau}, e->stream);
             return launch_status("memory read");
         };
-        // agg of the frame at sweep position g lives at w.agg + pos(g) * agg_fs
+        const bool off = offload && (batched || G == 1);           // unbatched groups of several frames reuse one agg slot: fused in line
+        float *const aggbuf = off && e->agg_buf ? w.agg_alt : w.agg;
+        if (off && e->fuse_pending[e->agg_buf]) {                  // the side stream may still read this buffer (two groups ago)
+            HIPCHK(hipStreamWaitEvent(e->stream, e->ev_fuse[e->agg_buf], 0));
+            e->fuse_pending[e->agg_buf] = 0;
+        }
+        // agg of the frame at sweep position g lives at aggbuf + pos(g) * agg_fs
         auto pos = [&](int g) { return batched ? (ti + g * step) - t_lo : 0; };
         if (batched) {
             const SlotPtrs &f0 = kf[forward ? 0 : G - 1];      // slot of frame t_lo
@@ -1076,14 +1096,14 @@ static int do_pass(stcn_engine *e, int idx, bool forward) {
                                    e->stream);
             }
             RC(launch_status("memory read (decode group)"));
-            RC(decode(*e->model, w, e->stream, w.readout, f0.f16_thin, f0.s8, f0.s4, w.agg, d.npix, f0.dthin, f0.cthin, G,
+            RC(decode(*e->model, w, e->stream, w.readout, f0.f16_thin, f0.s8, f0.s4, aggbuf, d.npix, f0.dthin, f0.cthin, G,
                       (long)e->slot_floats));
         }
         // ---- per frame, in sweep order: (unbatched: read + decode,) bank insertion, fusion / output
         for (int g = 0; g < G; ++g) {
             const int t = ti + g * step;
             const SlotPtrs &f = kf[g];
-            float *agg = w.agg + (size_t)pos(g) * agg_fs;
+            float *agg = aggbuf + (size_t)pos(g) * agg_fs;
             if (!batched) {
                 RC(read(f, w.readout));
                 dbg_sum(e, "k16", t, f.k16, (size_t)d.hw16 * 64);
@@ -1102,24 +1122,35 @@ static int do_pass(stcn_engine *e, int idx, bool forward) {
                 const float nc = (float)std::abs(closest - t) / (float)std::abs(closest - idx);
                 const float nr = (float)std::abs(idx - t) / (float)std::abs(closest - idx);
                 const int cs = e->n_certain - 1;               // key of the current interaction
+                Work &fw = off ? e->work_side : w;
+                hipStream_t fs = off ? e->side : e->stream;
+                if (off && g == 0) {                           // (groups decode in one pass: every agg of the group is final here)
+                    HIPCHK(hipEventRecord(e->ev_dec[e->agg_buf], e->stream));
+                    HIPCHK(hipStreamWaitEvent(e->side, e->ev_dec[e->agg_buf], 0));
+                }
                 {
-                    Scope sc(&e->prof, STCN_K_ATTENTION, e->stream, 2.0 * d.hw16 * d.hw16 * 64);
+                    Scope sc(&e->prof, STCN_K_ATTENTION, fs, 2.0 * d.hw16 * d.hw16 * 64);
                     attention_read_launch(e->bank_k + (size_t)cs * d.hw16 * 64, e->bank_msq + (size_t)cs * d.hw16, f.k16, nullptr,
-                                          nullptr, k + 1, d.h16, d.w16, w.pooled, w.amap, w.attn, AttnScratch{w.gmax, w.tau, w.cand_v}, e->stream);
+                                          nullptr, k + 1, d.h16, d.w16, w.pooled, fw.amap, fw.attn, AttnScratch{fw.gmax, fw.tau, fw.cand_v}, fs);
                 }
                 RC(launch_status("attention read"));
                 for (int o = 1; o <= k; ++o)
-                    RC(fusion_logit(*e->model, w, e->stream, e->images4 + (size_t)t * d.npix * 4, dst + (size_t)o * prs,
-                                    agg + (size_t)o * d.npix, w.attn + (size_t)o * 2 * d.npix, nc, nr,
-                                    w.flogit + (size_t)(o - 1) * d.npix));
-                Scope sc(&e->prof, STCN_K_ELEMWISE, e->stream);
-                sigmoid_aggregate_launch(w.flogit, k, d.npix, dst, prs, e->stream);
+                    RC(fusion_logit(*e->model, fw, fs, e->images4 + (size_t)t * d.npix * 4, dst + (size_t)o * prs,
+                                    agg + (size_t)o * d.npix, fw.attn + (size_t)o * 2 * d.npix, nc, nr,
+                                    fw.flogit + (size_t)(o - 1) * d.npix));
+                Scope sc(&e->prof, STCN_K_ELEMWISE, fs);
+                sigmoid_aggregate_launch(fw.flogit, k, d.npix, dst, prs, fs);
                 e->stats.fused++;
             } else {
                 Scope sc(&e->prof, STCN_K_ELEMWISE, e->stream);
                 copy_rows_launch(agg, d.npix, dst, prs, k + 1, d.npix, e->stream);
             }
             e->stats.frames++;
+        }
+        if (off) {                                                 // the side stream is done with this buffer when ev_fuse fires
+            HIPCHK(hipEventRecord(e->ev_fuse[e->agg_buf], e->side));
+            e->fuse_pending[e->agg_buf] = 1;
+            e->agg_buf ^= 1;
         }
         ti += G * step;
     }
@@ -1154,6 +1185,8 @@ static int interact_run(stcn_engine *e, const float *mask_dev, int mask_channels
     e->n_certain++;
     RC(do_pass(e, idx, true));
     RC(do_pass(e, idx, false));
+    for (int b = 0; b < 2; ++b)                                    // prob rows fused on the side stream are final before the argmax
+        if (e->fuse_pending[b]) { HIPCHK(hipStreamWaitEvent(e->stream, e->ev_fuse[b], 0)); e->fuse_pending[b] = 0; }
     {
         Scope sc(&e->prof, STCN_K_ELEMWISE, e->stream);
         argmax_launch(e->prob, kk, e->T, d.npix, e->masks, e->stream);
@@ -1197,6 +1230,7 @@ int stcn_interact(stcn_engine *e, const float *mask_dev, int mask_channels, int 
         if (!was_interacted) e->interacted.erase(idx);
         e->n_certain = n_certain0;
         std::fill(e->key_pending.begin(), e->key_pending.end(), 0);     // both streams are drained
+        e->fuse_pending[0] = e->fuse_pending[1] = 0;
         e->failed = why;
         set_error("%s", why.c_str());
     }

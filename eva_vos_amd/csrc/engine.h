@@ -95,6 +95,7 @@ struct Work {
     float *logit4 = nullptr;            // [k][hw4]
     float *flogit = nullptr;            // [k][npix]  fusion logits
     float *agg = nullptr;               // [k+1][npix] aggregated output of the current frame
+    float *agg_alt = nullptr;           // second buffer: decode groups alternate while the side stream fuses the previous group
     float *pooled = nullptr, *amap = nullptr, *attn = nullptr;   // attention read
     float *cand_v = nullptr; int32_t *cand_i = nullptr, *cand_n = nullptr;   // memory-read chunk winners
     float *gmax = nullptr, *tau = nullptr;                       // memory-read group maxima / thresholds
@@ -164,6 +165,11 @@ struct stcn_engine {
     std::vector<hipEvent_t> key_ready;   // per frame: recorded on `side` after its encode_key
     std::vector<char> key_pending;       // per frame: main stream has not yet waited on key_ready
     int lookahead = 0;
+    // FusionNet of a decoded group on the side stream (rounds >= 2: the side stream has no keys to encode), two agg buffers
+    bool fuse_side = false;
+    hipEvent_t ev_dec[2] = {nullptr, nullptr}, ev_fuse[2] = {nullptr, nullptr};
+    char fuse_pending[2] = {0, 0};       // ev_fuse[b] is recorded and the main stream has not waited for it yet
+    int agg_buf = 0;
     int key_batch = 1;                   // frames per key-encoder pass (env STCN_KEY_BATCH)
     int group = 1;                       // frames per memory-read + decoder pass (env STCN_DECODE_BATCH, k == 1)
     stcn::Prof prof;

@@ -116,7 +116,7 @@ if t2 and t1:
     md += ["", "Per launch class, HIP events (`python tools/r2_profile.py`, second pass):", "", "```"] + txt + ["```"]
     r2 = bench.get("roofline_r2") or {}
     if r2:
-        md += ["", f"bench.py `roofline_r2` of the same build (interact(mask, T//2) after interact(mask, 0)): {r2.get('frames_per_s_solo', 0):.0f} frames/s one video in flight, "
+        md += ["", f"bench.py `roofline_r2` of the same build (interact(mask, T//2) after interact(mask, 0)): {r2.get('frames_per_s_one_video', r2.get('frames_per_s_solo', 0)):.0f} frames/s one video in flight ({r2.get('frames_per_s_solo', 0):.0f} on one stream only), "
                f"{r2.get('frames_per_s_videos_in_flight', 0):.0f} with videos in flight; conv GEMMs (decoder + value encoder + FusionNet) {r2.get('achieved', 0):.1f} TFLOP/s executed = "
                f"{r2.get('frac', 0):.3f} of the fp32 MFMA peak; FusionNet convs {r2.get('fusion_conv_tflops', 0):.1f} TFLOP/s, {r2.get('fusion_conv_ms_per_fused_frame', 0) * 1e3:.0f} us per fused frame."]
     open(os.path.join(DST, f"{tag}_r2_kernel_stats.md"), "w").write("\n".join(md) + "\n")

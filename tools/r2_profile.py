@@ -12,7 +12,7 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["STCN_LOOKAHEAD"] = "0"
+os.environ.setdefault("STCN_LOOKAHEAD", "0")        # clean per-class attribution by default; STCN_LOOKAHEAD=2 for the shipped mode
 from eva_vos_amd import synth  # noqa: E402
 from eva_vos_amd.params import FusionNet, PropagationNetwork  # noqa: E402
 from mivos.inference_core import InferenceCore  # noqa: E402
