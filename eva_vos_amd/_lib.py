@@ -53,6 +53,7 @@ PROTOTYPES = {
     "stcn_metrics_jf_counts": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
     "stcn_bench_conv": (_I, [_P] + [_I] * 11 + [C.POINTER(_F), C.POINTER(_D)]),
     "stcn_bench_mfma_rate": (_I, [_P, _I, C.POINTER(_F), C.POINTER(_F)]),
+    "stcn_pool_release": (_I, []),
     "stcn_engine_set_profiling": (_I, [_P, _I]),
     "stcn_get_kernel_ms": (_I, [_P, C.POINTER(_F), C.POINTER(C.c_int32)]),
     "stcn_get_kernel_flops": (_I, [_P, C.POINTER(_D)]),

@@ -9,6 +9,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <unordered_map>
+#include <utility>
 
 namespace stcn {
 
@@ -268,12 +272,101 @@ static int build_model(Model &m, const stcn_weight_desc *prop, int n_prop, const
     return STCN_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- device-memory pool
+// The reference's drivers build one InferenceCore per sample (generate_fq_dataset.py:63-70, interactions/mask.py:24-26): an
+// engine's workspaces, key cache and bank are 4-8 GB of hipMalloc / hipFree per sample - 3-5 ms to create, 8-13 ms to destroy,
+// and every hipFree synchronises the DEVICE, i.e. stalls the other lanes' streams.  Engine buffers therefore come from a
+// per-device pool: a freed buffer (its engine's streams are drained before it is released) waits in a size class (steps of 1/8
+// of a power of two: <= 12.5 % slack) for the next engine; buffers are handed out uninitialised, as hipMalloc hands them out.
+// STCN_POOL_GB (default 64; 0: plain hipMalloc / hipFree) bounds what the pool keeps; stcn_pool_release() returns it all.
+namespace {
+struct DevPool {
+    std::mutex mu;
+    std::map<std::pair<int, size_t>, std::vector<void *>> free_;       // (device, size class) -> cached buffers
+    std::unordered_map<void *, std::pair<int, size_t>> live;           // buffers handed out
+    size_t cached = 0;
+    size_t cap() {
+        static const size_t c = [] { const char *e = getenv("STCN_POOL_GB"); return (size_t)(e ? atof(e) : 64.0) << 30; }();
+        return c;
+    }
+    static size_t size_class(size_t bytes) {
+        if (bytes <= (1u << 20)) return (bytes + 4095) / 4096 * 4096;
+        size_t step = 1;
+        while ((step << 4) <= bytes) step <<= 1;                         // step = 2^(floor(log2(bytes)) - 3)
+        return (bytes + step - 1) / step * step;
+    }
+};
+DevPool &pool() { static DevPool p; return p; }
+}  // namespace
+
+hipError_t pool_malloc(void **p, size_t bytes) {
+    DevPool &pl = pool();
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const size_t sc = DevPool::size_class(bytes);
+    if (pl.cap() > 0) {
+        std::lock_guard<std::mutex> g(pl.mu);
+        auto it = pl.free_.find({dev, sc});
+        if (it != pl.free_.end() && !it->second.empty()) {
+            *p = it->second.back();
+            it->second.pop_back();
+            pl.cached -= sc;
+            pl.live[*p] = {dev, sc};
+            // STCN_POOL_POISON=1 (tests): a recycled buffer arrives full of NaNs - anything read before it is written shows up
+            static const bool poison = [] { const char *e = getenv("STCN_POOL_POISON"); return e && atoi(e) != 0; }();
+            if (poison) { (void)hipMemset(*p, 0xFF, sc); (void)hipStreamSynchronize(nullptr); }     // the engines' streams do not wait for the null stream
+            return hipSuccess;
+        }
+    }
+    hipError_t er = hipMalloc(p, sc);
+    if (er != hipSuccess && pl.cap() > 0) {                              // out of memory with buffers parked in the pool: give them back, retry
+        (void)hipGetLastError();
+        pool_release();
+        er = hipMalloc(p, sc);
+    }
+    if (er == hipSuccess && pl.cap() > 0) {
+        std::lock_guard<std::mutex> g(pl.mu);
+        pl.live[*p] = {dev, sc};
+    }
+    return er;
+}
+
+void pool_free(void *p) {
+    if (!p) return;
+    DevPool &pl = pool();
+    {
+        std::lock_guard<std::mutex> g(pl.mu);
+        auto it = pl.live.find(p);
+        if (it != pl.live.end()) {
+            const auto key = it->second;
+            pl.live.erase(it);
+            if (pl.cached + key.second <= pl.cap()) {
+                pl.free_[key].push_back(p);
+                pl.cached += key.second;
+                return;
+            }
+        }
+    }
+    (void)hipFree(p);
+}
+
+void pool_release() {
+    DevPool &pl = pool();
+    std::vector<void *> all;
+    {
+        std::lock_guard<std::mutex> g(pl.mu);
+        for (auto &kv : pl.free_) { all.insert(all.end(), kv.second.begin(), kv.second.end()); kv.second.clear(); }
+        pl.cached = 0;
+    }
+    for (void *q : all) (void)hipFree(q);
+}
+
 // ---------------------------------------------------------------------------------------------- Work
 int Work::init(int nh, int nw, int k_, int key_batch, int group) {
     d.set(nh, nw);
     k = k_;
     auto alloc = [&](void **p, size_t bytes) -> int {
-        HIPCHK(hipMalloc(p, bytes));
+        HIPCHK(pool_malloc(p, bytes));
         allocs.push_back(*p);
         return STCN_OK;
     };
@@ -322,7 +415,7 @@ int Work::init(int nh, int nw, int k_, int key_batch, int group) {
     return STCN_OK;
 }
 void Work::release() {
-    for (void *p : allocs) (void)hipFree(p);
+    for (void *p : allocs) pool_free(p);
     allocs.clear();
 }
 
@@ -667,7 +760,7 @@ int stcn_model_destroy(stcn_model *m) {
 static int engine_init_outputs(stcn_engine *e);
 static int clone_state(stcn_engine *e, const stcn_engine *src);
 static int eng_alloc(stcn_engine *e, void **p, size_t bytes) {
-    HIPCHK(hipMalloc(p, bytes));
+    HIPCHK(pool_malloc(p, bytes));
     e->allocs.push_back(*p);
     return STCN_OK;
 }
@@ -695,7 +788,7 @@ static void bank_collect_retired(stcn_engine *e, bool wait) {
     if (e->retired.empty()) return;
     if (wait) (void)hipEventSynchronize(e->retire_ev);
     else if (hipEventQuery(e->retire_ev) != hipSuccess) return;
-    for (void *p : e->retired) (void)hipFree(p);
+    for (void *p : e->retired) pool_free(p);
     e->retired.clear();
 }
 
@@ -709,20 +802,20 @@ static int bank_reserve(stcn_engine *e, int slots) {
     while (cap < slots) cap *= 2;
     float *nk = nullptr, *nq = nullptr, *nv = nullptr;
     const size_t rows = (size_t)cap * d.hw16;
-    hipError_t er = hipMalloc((void **)&nk, rows * 64 * 4);
-    if (er == hipSuccess) er = hipMalloc((void **)&nq, (rows + 64) * 4);      // +64: the read kernels fetch msq in 64-row steps
-    if (er == hipSuccess) er = hipMalloc((void **)&nv, (size_t)e->k * rows * 512 * 4);
+    hipError_t er = pool_malloc((void **)&nk, rows * 64 * 4);
+    if (er == hipSuccess) er = pool_malloc((void **)&nq, (rows + 64) * 4);      // +64: the read kernels fetch msq in 64-row steps
+    if (er == hipSuccess) er = pool_malloc((void **)&nv, (size_t)e->k * rows * 512 * 4);
     if (er != hipSuccess) {
-        if (nk) (void)hipFree(nk);
-        if (nq) (void)hipFree(nq);
-        if (nv) (void)hipFree(nv);
+        if (nk) pool_free(nk);
+        if (nq) pool_free(nq);
+        if (nv) pool_free(nv);
         set_error("bank_reserve: %d slots (%zu MB) -> %s", cap, ((size_t)e->k * rows * 512 * 4 + rows * 65 * 4) >> 20, hipGetErrorString(er));
         return STCN_E_HIP;
     }
     // from here on a failure must release the three new buffers (callers may retry: several GB at 480p)
     auto fail = [&](hipError_t err, const char *what) {
         (void)hipStreamSynchronize(e->stream);              // copies into the new buffers may be in flight
-        (void)hipFree(nk); (void)hipFree(nq); (void)hipFree(nv);
+        pool_free(nk); pool_free(nq); pool_free(nv);
         set_error("bank_reserve: %s -> %s", what, hipGetErrorString(err));
         return STCN_E_HIP;
     };
@@ -747,8 +840,8 @@ static int bank_reserve(stcn_engine *e, int slots) {
 static int engine_alloc_common(stcn_engine *e) {
     const Dims &d = e->d;
     if (!e->images4) {                                     // a clone arrives with its source's packed clip
-        HIPCHK(hipMalloc((void **)&e->images4, (size_t)e->T * d.npix * 4 * 4));
-        e->images_owner = std::shared_ptr<void>(e->images4, [](void *p) { (void)hipFree(p); });
+        HIPCHK(pool_malloc((void **)&e->images4, (size_t)e->T * d.npix * 4 * 4));
+        e->images_owner = std::shared_ptr<void>(e->images4, [](void *p) { pool_free(p); });
     }
     e->n_slots = e->T < 106 ? e->T : 106;                 // key_buf holds at most 106 frames (inference_core.py:46,118)
     e->slot_floats = (size_t)d.hw16 * (64 + 512 + 1024) + (size_t)(d.hw16 + 3) / 4 * 4 + (size_t)d.hw8 * 512 + (size_t)d.hw4 * 256 +
@@ -853,8 +946,8 @@ int stcn_engine_destroy(stcn_engine *e) {
     for (hipEvent_t ev : e->key_ready) if (ev) (void)hipEventDestroy(ev);
     for (int b = 0; b < 2; ++b) { if (e->ev_dec[b]) (void)hipEventDestroy(e->ev_dec[b]); if (e->ev_fuse[b]) (void)hipEventDestroy(e->ev_fuse[b]); }
     e->work_side.release();
-    for (void *p : e->allocs) (void)hipFree(p);
-    if (e->bank_k) { (void)hipFree(e->bank_k); (void)hipFree(e->bank_msq); (void)hipFree(e->bank_v); }
+    for (void *p : e->allocs) pool_free(p);
+    if (e->bank_k) { pool_free(e->bank_k); pool_free(e->bank_msq); pool_free(e->bank_v); }
     bank_collect_retired(e, true);
     if (e->retire_ev) (void)hipEventDestroy(e->retire_ev);
     e->work.release();
@@ -1236,6 +1329,9 @@ int stcn_interact(stcn_engine *e, const float *mask_dev, int mask_channels, int 
     }
     return rc;
 }
+
+// returns the device memory parked in the engine-buffer pool (freed engines' workspaces) to the driver
+int stcn_pool_release(void) { pool_release(); return STCN_OK; }
 
 // test hook: the n-th launch-status check of the calling thread (counted from now) reports an injected failure
 int stcn_test_fail_at(int n) { inject_failure_after(n); return STCN_OK; }

@@ -18,6 +18,10 @@ void set_error(const char *fmt, ...);
 struct Model;
 struct ConvW;
 // builds the Winograd weights of a stride-1-capable 3x3 conv from its repacked fp32 host weights (no-op when not eligible)
+// engine buffers come from a per-device pool (engine.cpp: a hipFree per buffer synchronises the device and stalls the other lanes)
+hipError_t pool_malloc(void **p, size_t bytes);
+void pool_free(void *p);
+void pool_release();
 int make_wino(Model &m, ConvW &cw, const std::vector<float> &w_host);
 // F(4x4,3x3) weights of a decoder-side 3x3 conv (no-op when not eligible)
 int make_wino4(Model &m, ConvW &cw, const std::vector<float> &w_host);

@@ -81,6 +81,11 @@ def forget_models() -> None:
         _MODEL_CACHE.clear()
 
 
+def release_pooled_memory() -> None:
+    """Return the device memory of destroyed engines (parked in the library's buffer pool for the next engine) to the driver."""
+    _lib.check(_lib.lib().stcn_pool_release(), "stcn_pool_release")
+
+
 def _model_for(prop_net, fuse_net, device_index: int) -> _Model:
     """The engine works on a BN-folded, repacked SNAPSHOT of the weights.  The reference reads the live parameters, so the
     snapshot is keyed on a fingerprint of both modules' tensors: loading another checkpoint into the same module objects

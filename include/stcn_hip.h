@@ -161,6 +161,12 @@ int stcn_test_fusion(const stcn_model *m, void *stream, const float *img, const 
  * steps per pass-2 chunk }.  Lets tests assert WHICH plan (sample stride 1/2/4/8) a comparison exercised. */
 int stcn_memread_plan(int N, int Q, int32_t *plan7);
 
+/* Engine buffers (workspaces, key cache, memory bank, packed clip) come from a per-device pool: a destroyed engine's buffers
+ * wait there for the next engine of the same sizes (the reference's drivers build one InferenceCore per sample; a hipFree
+ * per buffer would synchronise the device under the other videos in flight).  STCN_POOL_GB bounds the pool (default 64, 0 = off);
+ * this call returns everything it holds to the driver. */
+int stcn_pool_release(void);
+
 /* Test hook (fault injection): the n-th kernel-launch status check made by the CALLING THREAD from now on reports a
  * failure (n = 0 disarms).  Used to show that a failing stcn_interact leaves the engine in a defined state. */
 int stcn_test_fail_at(int n);

@@ -578,3 +578,43 @@ def test_480p_multi_object_decode_groups_match_the_oracle(nets, weights):
         assert q999 <= 3 * float(noise[2]) + 5e-4, (idx, q999)
     s_ = core.stats()
     assert s_["fused"] > 0 and s_["frames"] == T - 2
+
+
+_POOL_SCRIPT = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from eva_vos_amd import synth
+from eva_vos_amd.inference_core import release_pooled_memory
+from eva_vos_amd.params import FusionNet, PropagationNetwork
+from mivos.inference_core import InferenceCore
+torch.set_grad_enabled(False)
+prop, fuse = PropagationNetwork(), FusionNet()
+prop.load_state_dict(synth.recipe_state_dict(prop)); fuse.load_state_dict(synth.recipe_state_dict(fuse))
+T = 11
+img = synth.synthetic_clip(T, 128, 160).cuda()
+gt = synth.synthetic_mask(T, 128, 160, 1)
+outs = []
+for rep in range(3):                        # engines 2 and 3 run in the recycled (NaN-filled) buffers of their predecessors
+    e = InferenceCore(prop, fuse, img, 1, mem_freq=3)
+    m1 = e.interact(gt[:, 0], 0).copy()
+    m2 = e.interact(gt[:, 6], 6).copy()     # a fused round: side-stream workspace too
+    assert torch.isfinite(e.prob).all()
+    outs.append((m1, m2, e.prob.clone()))
+    del e
+for m1, m2, p in outs[1:]:
+    assert (m1 == outs[0][0]).all() and (m2 == outs[0][1]).all() and torch.equal(p, outs[0][2])
+release_pooled_memory()
+print("POOL-OK")
+"""
+
+
+def test_recycled_engine_buffers_carry_nothing_over():
+    """Engine buffers come from a per-device pool (a destroyed engine's workspaces serve the next engine).  Under
+    STCN_POOL_POISON=1 a recycled buffer arrives full of NaNs: three engines in a row must produce bit-identical, finite results."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, STCN_POOL_POISON="1")
+    r = subprocess.run([sys.executable, "-c", _POOL_SCRIPT % root], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "POOL-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
