@@ -174,7 +174,7 @@ class InferenceCore:
                 return None
             lw, uw, lh, uh = self.pad
             out = self.masks[:, 0, lh:self.nh - uh, lw:self.nw - uw]
-            self.np_masks = out.cpu().numpy().astype(np.uint8)     # D2H sync, as the reference's .cpu()
+            self.np_masks = out.cpu().numpy().astype(np.uint8, copy=False)     # D2H sync, as the reference's .cpu(); a fresh array per call
         return self.np_masks
 
     # The engine enqueues on the HIP stream that was current when the core was constructed.  Normal PyTorch stream
