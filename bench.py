@@ -549,7 +549,7 @@ def main():
         """Host thread `lane`: takes the next video of the step counter whenever its previous one is done (ctypes releases the
         GIL), runs it on its own stream with its own engines; no lane idles while videos are left."""
         torch.cuda.set_device(local)
-        fr, out, prev, same, n = 0, None, {}, True, 0
+        fr, out, outs, n = 0, None, [], 0
         with torch.cuda.stream(streams[lane]):
             while True:
                 with lock:
@@ -561,12 +561,19 @@ def main():
                     e.reset()
                 out = e.interact(mask, idx, scribble=K_OBJ > 1)
                 fr += e.stats()["frames"]
-                if fresh:                                   # same engine = same clip: repeats must be bit-identical
-                    if n % per_lane in prev:
-                        same = same and np.array_equal(prev[n % per_lane], out)
-                    prev[n % per_lane] = out
+                if fresh:
+                    outs.append((n % per_lane, out))        # compared AFTER the timed region (27 MB each: harness work, not the path's)
                 n += 1
-        return fr, out, same, (n - 1) % per_lane if n else 0, prev
+        return fr, out, outs, (n - 1) % per_lane if n else 0
+
+    def repeats_identical(outs):
+        """same engine = same clip: the repeated videos of a lane must be bit-identical"""
+        prev, same = {}, True
+        for slot, o in outs:
+            if slot in prev:
+                same = same and np.array_equal(prev[slot], o)
+            prev[slot] = o
+        return same
 
     def run_all(mask, idx, fresh=True):
         ticket, lock = itertools.count(), threading.Lock()
@@ -592,7 +599,7 @@ def main():
         e = pool[l0][res[l0][3]]
         e.reset()
         solo = e.interact(mask0, 0, scribble=K_OBJ > 1)
-    lanes_identical = all(r[2] for r in res) and np.array_equal(solo, last)
+    lanes_identical = all(repeats_identical(r[2]) for r in res) and np.array_equal(solo, last)
 
     # Roofline leg: the same step (fresh engine, interact(mask,0)) on ONE stream with per-launch HIP events on
     # that stream.  Kept apart from the timed region on purpose: (i) two events per launch cost ~13 % of
