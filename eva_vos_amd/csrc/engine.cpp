@@ -853,7 +853,8 @@ static int engine_alloc_common(stcn_engine *e) {
     RC(eng_alloc(e, (void **)&e->pos, (size_t)(e->k + 1) * d.npix * 4));
     RC(eng_alloc(e, (void **)&e->neg, (size_t)(e->k + 1) * d.npix * 4));
     const char *la = getenv("STCN_LOOKAHEAD");
-    e->lookahead = la ? atoi(la) : 2;
+    const int la_env = la ? atoi(la) : 2;                 // 0: no side stream at all (profiling legs: solo launches only)
+    e->lookahead = la_env;
     if (e->T > e->n_slots) e->lookahead = 0;
     const char *gb = getenv("STCN_DECODE_BATCH");
     e->group = gb ? atoi(gb) : 8;
@@ -869,16 +870,20 @@ static int engine_alloc_common(stcn_engine *e) {
     e->work.prof = &e->prof;
     // Look-ahead is only used when no cache slot is ever recycled (T <= slots): the key encoder of the
     // next frames then runs on a side stream concurrently with the memory-read / decoder chain.
-    if (e->lookahead > 0) {
+    // The side stream also runs FusionNet in rounds >= 2 (fuse_side), which does not depend on the cache policy: clips longer
+    // than the key cache (MOSE) keep it for that alone.
+    const char *fs = getenv("STCN_FUSE_SIDE");
+    e->fuse_side = la_env > 0 && e->model->has_fuse && (!fs || atoi(fs) != 0);
+    if (e->lookahead > 0 || e->fuse_side) {
         HIPCHK(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
-        RC(e->work_side.init(d.nh, d.nw, e->k, e->key_batch));          // k objects: it also runs FusionNet (fuse_side)
+        RC(e->work_side.init(d.nh, d.nw, e->k, e->lookahead > 0 ? e->key_batch : 1));      // k objects: it also runs FusionNet
         e->work_side.prof = &e->prof;
-        const char *fs = getenv("STCN_FUSE_SIDE");
-        e->fuse_side = !fs || atoi(fs) != 0;
         for (int b = 0; b < 2 && e->fuse_side; ++b) {
             HIPCHK(hipEventCreateWithFlags(&e->ev_dec[b], hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&e->ev_fuse[b], hipEventDisableTiming));
         }
+    }
+    if (e->lookahead > 0) {
         e->key_ready.assign(e->T, nullptr);
         for (int t = 0; t < e->T; ++t) HIPCHK(hipEventCreateWithFlags(&e->key_ready[t], hipEventDisableTiming));
     }
@@ -999,6 +1004,10 @@ static int clone_state(stcn_engine *e, const stcn_engine *src) {
 // a missing frame (on the side stream when look-ahead is on); ensure_key() additionally orders the main
 // stream behind it.
 static void flush_key_cache(stcn_engine *e) {                // flush-all policy of the reference
+    // recycled slots are rewritten on the main stream: it first waits for the side stream's FusionNet of earlier groups, which
+    // reads k16 out of those slots (long clips: T > slots)
+    for (int b = 0; b < 2; ++b)
+        if (e->fuse_pending[b]) { (void)hipStreamWaitEvent(e->stream, e->ev_fuse[b], 0); e->fuse_pending[b] = 0; }
     std::fill(e->slot_of.begin(), e->slot_of.end(), -1);
     std::fill(e->vparts_ready.begin(), e->vparts_ready.end(), 0);
     e->n_cached = 0;
