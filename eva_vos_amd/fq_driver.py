@@ -125,6 +125,10 @@ def run_lanes(root: str, imset: str, mine, lanes: int, work, device: str = "cuda
     on_gpu = torch.cuda.is_available() and str(device).startswith("cuda")
     dev_index = torch.cuda.current_device() if on_gpu else None
     bounds = [len(mine) * l // lanes for l in range(lanes + 1)]
+    if lanes > 1:
+        # the engines' own side streams (key-encoder look-ahead, FusionNet of rounds >= 2) help ONE video in flight (+6..8 %);
+        # with several lanes the videos already fill each other's gaps and eight streams only contend (second interactions -3 %)
+        os.environ.setdefault("STCN_LOOKAHEAD", "0")
 
     def lane(l):
         ds = ClipDataset(root, imset)
