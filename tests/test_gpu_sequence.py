@@ -618,3 +618,32 @@ def test_recycled_engine_buffers_carry_nothing_over():
     env = dict(os.environ, STCN_POOL_POISON="1")
     r = subprocess.run([sys.executable, "-c", _POOL_SCRIPT % root], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "POOL-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def _random_sessions():
+    rng = np.random.RandomState(20260304)
+    cases = []
+    for _ in range(6):
+        T = int(rng.randint(8, 25))
+        mf = int(rng.choice([1, 2, 3, 5, 7]))
+        H, W = int(rng.choice([112, 120, 136])), int(rng.choice([128, 150, 176]))
+        rounds = [int(v) for v in rng.choice(T, size=3, replace=False)]
+        cases.append((T, H, W, mf, tuple(rounds)))
+    return cases
+
+
+@pytest.mark.parametrize("T,H,W,mf,rounds", _random_sessions())
+def test_random_annotation_sessions_match_the_oracle(T, H, W, mf, rounds, nets, weights):
+    """Seeded sweep over what the fixed cases cannot enumerate: clip length, frame size (ragged pads), mem_freq and the ORDER of
+    three interactions (first / last frames, neighbours, fused spans of any length) - HIP engine against the oracle after every
+    round, same statements as the goldens (mask bounds + max-norm on the frames before the first near-tie)."""
+    img = synth.synthetic_clip(T, H, W, seed=31 + T)
+    msk = synth.synthetic_mask(T, H, W, 1, seed=32 + T)
+    core = make_core(nets)(img, 1, mf)
+    orc = O.OracleCore(weights[0], weights[1], img, 1, mem_freq=mf)
+    for r, idx in enumerate(rounds):
+        a, b = core.interact(msk[:, idx], idx), orc.interact(msk[:, idx], idx)
+        tag = f"random T={T} {H}x{W} mf={mf} rounds={rounds}"
+        masks_close(a, b, 1, f"{tag} r{r}")
+        clean_frame_check(core.prob.cpu(), orc, r, tag)
+    assert core.stats()["frames"] > 0
