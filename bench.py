@@ -61,6 +61,11 @@ def parse():
                     help="skip the extra davis_val object (the 30-length workload measured beside the uniform headline)")
     ap.add_argument("--config3-oracle-frames", type=int, default=8,
                     help="frames of the config-3 parity sample (k objects, mem_freq=1) run on the CPU oracle AND the HIP engine; 0 = skip")
+    ap.add_argument("--parity-long-frames", type=int, default=104,
+                    help="frames of the long-clip parity leg (k=1, CPU oracle AND HIP engine, ~35 s of host time at 104); 0 = skip")
+    ap.add_argument("--parity-session-rounds", type=int, default=8,
+                    help="rounds of the annotation-session parity leg (oracle mask policy, CPU oracle AND HIP engine); 0 = skip")
+    ap.add_argument("--parity-session-frames", type=int, default=34, help="clip length of the session parity leg (shortest DAVIS-val clip)")
     ap.add_argument("--no-config3", dest="config3", action="store_false",
                     help="skip the extra config-3 leg (k=5 objects, mem_freq=1, T=104: full-length bank)")
     ap.add_argument("--config3-frames", type=int, default=104)
@@ -115,7 +120,7 @@ def cpu_baseline(psd, fsd, H, W, frames, mem_freq):
     return base, (img, msk, ref1, ref2)
 
 
-def parity_vs_oracle(prop, fuse, sample, mem_freq):
+def parity_vs_oracle(prop, fuse, sample, mem_freq, eo=None):
     """The HIP engine on the clip the CPU oracle just processed, both rounds: mask IoU between the two, frames/s of the same
     two interactions on the GPU (one video in flight), and J&F of each against the synthetic ground truth - the CPU masks
     scored by the CPU restatement of interactions/metrics.py, the HIP masks by the HIP J/F kernel (north_star: masks within
@@ -124,7 +129,7 @@ def parity_vs_oracle(prop, fuse, sample, mem_freq):
     from mivos.inference_core import InferenceCore
     img, msk, ref1, ref2 = sample
     mid = img.shape[1] // 2
-    core = InferenceCore(prop, fuse, img.cuda(), 1, mem_freq=mem_freq)
+    core = InferenceCore(prop, fuse, img.cuda(), 1, mem_freq=mem_freq, engine_options=eo)
     core.interact(msk[:, 0], 0)                         # warm-up (allocations, first-launch costs), then a fresh state
     core.reset()
     torch.cuda.synchronize()
@@ -217,9 +222,8 @@ def config3_leg(prop, fuse, T, H, W, k):
     img = synth.synthetic_clip(T, H, W).cuda()
     gt = synth.synthetic_mask(T, H, W, k)
     m0 = torch.cat([1 - gt[:, 0].sum(0, keepdim=True).clamp(0, 1), gt[:, 0]], 0)
-    la_saved = os.environ.get("STCN_LOOKAHEAD")
-    os.environ["STCN_LOOKAHEAD"] = "2"                      # one video in flight: key encoder ahead on a side stream
-    e = InferenceCore(prop, fuse, img, k, mem_freq=1)
+    # one video in flight: key encoder ahead on a side stream (engine options are passed explicitly: no os.environ traffic)
+    e = InferenceCore(prop, fuse, img, k, mem_freq=1, engine_options={"lookahead": 2})
     e.interact(m0, 0, scribble=True)                       # warm-up
     e.reset()
     torch.cuda.synchronize()
@@ -228,8 +232,7 @@ def config3_leg(prop, fuse, T, H, W, k):
     dt = time.perf_counter() - t0
     st = e.stats()
     del e
-    os.environ["STCN_LOOKAHEAD"] = "0"
-    e = InferenceCore(prop, fuse, img, k, mem_freq=1)
+    e = InferenceCore(prop, fuse, img, k, mem_freq=1, engine_options={"lookahead": 0})
     e.set_profiling(True)
     out2 = e.interact(m0, 0, scribble=True)
     torch.cuda.synchronize()
@@ -237,7 +240,6 @@ def config3_leg(prop, fuse, T, H, W, k):
     prof.pop("conv_hbm_bound")
     del e
     torch.cuda.empty_cache()
-    os.environ["STCN_LOOKAHEAD"] = la_saved if la_saved is not None else "2"
     tot = sum(v["ms"] for v in prof.values())
     conv, mr = prof["conv"], prof["memread"]
     return {"workload": f"{H}x{W} {k}-object engine (scribble / (k+1)-channel path), mem_freq=1, T={T}: interact(mask,0) on a fresh engine; "
@@ -259,10 +261,9 @@ DAVIS_VAL_LENGTHS = [69, 50, 80, 84, 90, 75, 40, 104, 90, 60, 66, 52, 50, 90, 78
 
 def config3_parity(prop, fuse, psd, fsd, T, H, W, k):
     """BASELINE config 3's shape on the CPU oracle AND the HIP engine (first T frames: k objects through the scribble path,
-    mem_freq = 1): per-object mask IoU - over all pixels and over the pixels whose label is well-conditioned in the ORACLE's
-    own probabilities (top-1 minus top-2 >= 1e-2; with several objects the random-recipe decoder leaves large regions at
-    p ~ 1/(k+1) in every row, where the argmax hangs on the last ulp: tests/test_oracle_golden.py, seq480k5) - the worst
-    frame, and the probability difference."""
+    mem_freq = 1) under the MULTI-OBJECT weight recipe (synth.RECIPES[2]: the decoder separates the objects, so the reference's
+    own top-1 minus top-2 margin is >= 1e-2 on > 99 % of the pixels - tests/golden/seq480k5): per-object mask IoU over ALL pixels
+    (bar 1 - 1e-3), the worst frame, the probability difference; the fraction of decisive pixels is reported beside it."""
     from eva_vos_amd import synth
     from mivos.inference_core import InferenceCore
     from oracle.stcn_oracle import OracleCore
@@ -281,23 +282,96 @@ def config3_parity(prop, fuse, psd, fsd, T, H, W, k):
     dec = ((top[0] - top[1]) >= 1e-2).numpy()
     d = (po - pg).abs()
     out = dict(sample=f"first {T} frames of the config-3 workload ({H}x{W}, k={k}, mem_freq=1), interact(mask,0): CPU oracle {t_cpu:.1f} s",
+               weights="synthetic multi-object recipe (seed 2: Philox draws + decoder.pred fitted on reference features, oracle/fit_multi_pred.py)",
                decisive_pixel_fraction=float(dec[1:].mean()), mask_pixels_differing=int((got != ref).sum()),
                mask_pixels_differing_on_decisive=int(((got != ref) & dec).sum()), mask_pixels_total=int(got.size),
+               object_pixels_per_frame_min=[int((ref[1:] == o).reshape(T - 1, -1).sum(1).min()) for o in range(1, k + 1)],
                prob_abs_diff_p999=float(torch.quantile(d.flatten()[::7], 0.999)), prob_abs_diff_max=float(d.max()))
-    ious, ious_dec, fmin = [], [], 1.0
+    ious, fmin, fwhere = [], 1.0, None
     for o in range(1, k + 1):
         a_, b_ = got == o, ref == o
         ious.append(float((a_ & b_).sum() / max((a_ | b_).sum(), 1)))
-        a_, b_ = a_ & dec, b_ & dec
-        ious_dec.append(float((a_ & b_).sum() / max((a_ | b_).sum(), 1)))
         fu, fi = (a_ | b_).reshape(T, -1).sum(1), (a_ & b_).reshape(T, -1).sum(1)
-        fmin = min(fmin, float(np.where(fu >= 64, fi / np.maximum(fu, 1), 1.0).min()))
-    out.update(mask_iou_vs_cpu_oracle_per_object=ious, mask_iou_vs_cpu_oracle_per_object_decisive_pixels=ious_dec,
-               mask_iou_vs_cpu_oracle=min(ious_dec), min_frame_iou_decisive_pixels=fmin,
-               what="mask_iou_vs_cpu_oracle = worst object on the decisive pixels (bar 1 - 1e-3); the all-pixel IoU is given beside it")
+        fiou = np.where(fu >= 64, fi / np.maximum(fu, 1), 1.0)
+        if float(fiou.min()) < fmin:
+            fmin, fwhere = float(fiou.min()), (o, int(fiou.argmin()))
+    out.update(mask_iou_vs_cpu_oracle_per_object=ious, mask_iou_vs_cpu_oracle=min(ious), min_frame_iou=fmin, min_frame_iou_object_frame=fwhere,
+               what="mask_iou_vs_cpu_oracle = worst object over ALL pixels of the clip (bar 1 - 1e-3); min_frame_iou = worst (object, frame)")
     del core
     torch.cuda.empty_cache()
     return out
+
+
+def long_clip_parity(prop, fuse, psd, fsd, H, W, T, mem_freq, eo=None):
+    """The longest DAVIS / MOSE clip length (T = 104, download_data.py:42) at 480p on the CPU oracle AND the HIP engine: one first
+    interaction, k = 1.  Per frame IoU along the clip - does the difference grow towards the end of a long propagation?"""
+    from eva_vos_amd import synth
+    from mivos.inference_core import InferenceCore
+    from oracle.stcn_oracle import OracleCore
+    img, msk = synth.synthetic_clip(T, H, W), synth.synthetic_mask(T, H, W, 1)
+    t0 = time.perf_counter()
+    ref = OracleCore(psd, fsd, img, 1, mem_freq=mem_freq).interact(msk[:, 0], 0)
+    t_cpu = time.perf_counter() - t0
+    core = InferenceCore(prop, fuse, img.cuda(), 1, mem_freq=mem_freq, engine_options=eo)
+    got = core.interact(msk[:, 0], 0)
+    a_, b_ = got > 0, ref > 0
+    fu, fi = (a_ | b_).reshape(T, -1).sum(1), (a_ & b_).reshape(T, -1).sum(1)
+    fiou = np.where(fu >= 64, fi / np.maximum(fu, 1), 1.0)
+    quarters = [float(fiou[q * T // 4:(q + 1) * T // 4].min()) for q in range(4)]
+    del core
+    torch.cuda.empty_cache()
+    return dict(clip=f"{T} frames {H}x{W}, k=1, mem_freq={mem_freq}, interact(mask,0): CPU oracle {t_cpu:.1f} s ({(T - 1) / t_cpu:.2f} frames/s)",
+                mask_iou_hip_vs_cpu_oracle=float((a_ & b_).sum() / max((a_ | b_).sum(), 1)), mask_pixels_differing=int((a_ != b_).sum()),
+                mask_pixels_total=int(got.size), min_frame_iou=float(fiou.min()), min_frame_iou_frame=int(fiou.argmin()),
+                min_frame_iou_by_quarter_of_the_clip=quarters, bar="1 - 1e-3 on the clip and on every frame")
+
+
+def session_parity(prop, fuse, psd, fsd, H, W, T, rounds, mem_freq, eo=None):
+    """A whole ANNOTATION SESSION at 480p on the CPU oracle AND the HIP engine: the oracle policy of the reference
+    (interactions/mask.py:113-146: annotate frame 0, then after every round the frame with the worst J against the ground truth;
+    annotated frames count with their ground-truth mask, interactions/eval.py:57-60) for `rounds` rounds - growing certain
+    memory, shrinking spans, fusion on both sides of earlier interactions.  Both follow the ORACLE's frame choices (so that the
+    comparison is of propagation, not of a tie in the policy); whether the HIP engine's own J picks the same frame is reported."""
+    from eva_vos_amd import synth
+    from mivos.inference_core import InferenceCore
+    from oracle.stcn_oracle import OracleCore
+    img, msk = synth.synthetic_clip(T, H, W, seed=7), synth.synthetic_mask(T, H, W, 1, seed=7)
+    gtb = msk[0, :, 0].numpy() > 0.5
+    orc = OracleCore(psd, fsd, img, 1, mem_freq=mem_freq)
+    core = InferenceCore(prop, fuse, img.cuda(), 1, mem_freq=mem_freq, engine_options=eo)
+
+    def per_frame_j(masks, done):
+        gen = masks > 0
+        gen[done] = gtb[done]
+        u, n = (gen | gtb).reshape(T, -1).sum(1), (gen & gtb).reshape(T, -1).sum(1)
+        return np.where(u > 0, n / np.maximum(u, 1), 0.0)
+
+    frames, rows, t_cpu, t_gpu = [0], [], 0.0, 0.0
+    for r in range(rounds):
+        f = frames[r]
+        t0 = time.perf_counter()
+        ref = orc.interact(msk[:, f], f).copy()
+        t1 = time.perf_counter()
+        got = core.interact(msk[:, f], f).copy()
+        t2 = time.perf_counter()
+        t_cpu, t_gpu = t_cpu + t1 - t0, t_gpu + t2 - t1
+        a_, b_ = got > 0, ref > 0
+        fu, fi = (a_ | b_).reshape(T, -1).sum(1), (a_ & b_).reshape(T, -1).sum(1)
+        fiou = np.where(fu >= 64, fi / np.maximum(fu, 1), 1.0)
+        q_ref, q_got = per_frame_j(ref, frames[:r + 1]), per_frame_j(got, frames[:r + 1])
+        nxt = int(np.argmin(q_ref))
+        rows.append(dict(round=r + 1, frame=int(f), mask_iou=float((a_ & b_).sum() / max((a_ | b_).sum(), 1)), mask_pixels_differing=int((a_ != b_).sum()),
+                         min_frame_iou=float(fiou.min()), min_frame_iou_frame=int(fiou.argmin()), mean_j_oracle=float(q_ref.mean()), mean_j_hip=float(q_got.mean()),
+                         next_frame_oracle=nxt, next_frame_hip=int(np.argmin(q_got))))
+        frames.append(nxt)
+    st = core.stats()
+    del core
+    torch.cuda.empty_cache()
+    return dict(session=f"{rounds} rounds of the oracle mask policy (interactions/mask.py:113-146) on a {T}-frame {H}x{W} clip, k=1, mem_freq={mem_freq}; "
+                        f"CPU oracle {t_cpu:.1f} s, HIP engine {t_gpu:.2f} s", frames_annotated=[int(v) for v in frames[:rounds]],
+                worst_round_mask_iou=min(r_["mask_iou"] for r_ in rows), worst_round_min_frame_iou=min(r_["min_frame_iou"] for r_ in rows),
+                same_frame_choice_every_round=all(r_["next_frame_oracle"] == r_["next_frame_hip"] for r_ in rows),
+                last_round_stats=st, rounds=rows, bar="1 - 1e-3 per round on the clip and on every frame")
 
 
 def r2_roofline(prop, fuse, img, mask0, mask_mid, T, mem_freq, scribble):
@@ -309,8 +383,8 @@ def r2_roofline(prop, fuse, img, mask0, mask_mid, T, mem_freq, scribble):
     res = {}
     # the shipped mode first (side stream on: FusionNet of a decoded group runs beside the next group), then one stream only;
     # the first pair of interactions of the process is a warm-up (first launches of the rounds >= 2 kernels)
-    def one_r2(prof_on=False):
-        e = InferenceCore(prop, fuse, img, 1 if not scribble else mask0.shape[0] - 1, mem_freq=mem_freq)
+    def one_r2(prof_on=False, la=2):
+        e = InferenceCore(prop, fuse, img, 1 if not scribble else mask0.shape[0] - 1, mem_freq=mem_freq, engine_options={"lookahead": la})
         e.interact(mask0, 0, scribble=scribble)
         e.set_profiling(prof_on)
         torch.cuda.synchronize()
@@ -319,24 +393,21 @@ def r2_roofline(prop, fuse, img, mask0, mask_mid, T, mem_freq, scribble):
         torch.cuda.synchronize()
         return e, time.perf_counter() - t0
 
-    la_saved = os.environ.get("STCN_LOOKAHEAD")
-    os.environ["STCN_LOOKAHEAD"] = "2"                     # the engine's default: side stream on (the lanes of this bench run without)
     rates = []
     for i in range(4):                                     # first pair = warm-up; median of three 50 ms measurements
-        e, dt = one_r2()
+        e, dt = one_r2(la=2)                               # the engine's default: side stream on (the lanes of this bench run without)
         if i:
             rates.append(e.stats()["frames"] / dt)
         del e
     res["frames_per_s_one_video"] = sorted(rates)[1]
-    os.environ["STCN_LOOKAHEAD"] = "0"
     rates = []
     for i in range(3):
-        e, dt = one_r2()
+        e, dt = one_r2(la=0)
         rates.append(e.stats()["frames"] / dt)
         del e
     res["frames_per_s_solo"] = sorted(rates)[1]
     for prof_on in (True,):
-        e = InferenceCore(prop, fuse, img, 1 if not scribble else mask0.shape[0] - 1, mem_freq=mem_freq)
+        e = InferenceCore(prop, fuse, img, 1 if not scribble else mask0.shape[0] - 1, mem_freq=mem_freq, engine_options={"lookahead": 0})
         e.interact(mask0, 0, scribble=scribble)
         e.set_profiling(prof_on)
         torch.cuda.synchronize()
@@ -348,10 +419,6 @@ def r2_roofline(prop, fuse, img, mask0, mask_mid, T, mem_freq, scribble):
         prof = e.kernel_profile()
         prof.pop("conv_hbm_bound")
         del e
-    if la_saved is None:
-        os.environ.pop("STCN_LOOKAHEAD")
-    else:
-        os.environ["STCN_LOOKAHEAD"] = la_saved
     tot = sum(v["ms"] for v in prof.values())
     conv, fus = prof["conv"], prof["fusion_conv"]
     gemm_ms = conv["ms"] + fus["ms"]
@@ -374,7 +441,7 @@ def r2_roofline(prop, fuse, img, mask0, mask_mid, T, mem_freq, scribble):
     return res
 
 
-def davis_val_leg(prop, fuse, a, H, W, rank, world, local, streams, barrier):
+def davis_val_leg(prop, fuse, a, H, W, rank, world, local, streams, barrier, eo=None):
     """samples with the 30 DAVIS-2017-val sequence lengths, assigned to the ranks by LPT on their
     frame counts (eva_vos_amd.shard.lpt_assign; the reference slices by --min-idx/--max-idx, eval_annotation_method.py:34-35,
     113-119), inside a rank to the in-flight lanes the same way.  Fixed total work -> strong scaling: frames of ALL samples /
@@ -397,7 +464,7 @@ def davis_val_leg(prop, fuse, a, H, W, rank, world, local, streams, barrier):
             for i in part:
                 g = torch.Generator(device="cuda").manual_seed(5000 + i)
                 clip = base[:, :lengths[i]] + 0.15 * torch.randn((1, lengths[i]) + tuple(base.shape[2:]), generator=g, device="cuda")
-                engines[i] = InferenceCore(prop, fuse, clip, 1, mem_freq=a.mem_freq)
+                engines[i] = InferenceCore(prop, fuse, clip, 1, mem_freq=a.mem_freq, engine_options=eo)
     del base
     torch.cuda.synchronize()
     frames = [0] * S
@@ -516,7 +583,10 @@ def main():
     S = max(1, min(a.streams, n_uniform))
     # engine knob: key-encoder look-ahead on a side stream helps a single video in flight (+6 %) but only
     # adds contention when several videos already overlap
-    os.environ.setdefault("STCN_LOOKAHEAD", "0" if S > 1 else "2")
+    # (given to every engine explicitly - stcn_engine_create_ex - instead of through os.environ, which other lanes' host threads
+    # would read while a later leg changes it; an STCN_LOOKAHEAD set by the user still decides the lanes' value)
+    la_main = int(os.environ.get("STCN_LOOKAHEAD", "0" if S > 1 else "2"))
+    eo_main = {"lookahead": la_main}
     streams = [torch.cuda.Stream() for _ in range(S)] if S > 1 else [torch.cuda.current_stream()]
     # A bounded pool of engines (each ~5.5 GB at T=66) serves any --steps: lane l owns engines pool[l]; a video
     # takes the lane's next engine and resets it first (reset = what a fresh InferenceCore would hold).  Every engine of
@@ -533,7 +603,7 @@ def main():
 
     def make(lane, j=0):
         with torch.cuda.stream(streams[lane]):
-            return InferenceCore(prop, fuse, clips[lane][j], K_OBJ, mem_freq=a.mem_freq)
+            return InferenceCore(prop, fuse, clips[lane][j], K_OBJ, mem_freq=a.mem_freq, engine_options=eo_main)
 
     pool = [[make(l, j) for j in range(per_lane)] for l in range(S)]
     pad_hw = (pool[0][0].nh, pool[0][0].nw)
@@ -621,10 +691,8 @@ def main():
     if not a.no_profile:
         prof = {}
         roof_frames, t_roof = 0, 0.0
-        la_saved = os.environ.get("STCN_LOOKAHEAD")
-        os.environ["STCN_LOOKAHEAD"] = "0"            # solo launches only: no side-stream overlap in this leg
         for _ in range(max(1, a.roof_steps)):
-            e = InferenceCore(prop, fuse, img, K_OBJ, mem_freq=a.mem_freq)
+            e = InferenceCore(prop, fuse, img, K_OBJ, mem_freq=a.mem_freq, engine_options={"lookahead": 0})   # solo launches only: no side-stream overlap in this leg
             e.set_profiling(True)
             torch.cuda.synchronize()
             tr = time.perf_counter()
@@ -640,7 +708,6 @@ def main():
                     for k_ in ("wino2_flops", "wino4_flops"):
                         acc[k_] = acc.get(k_, 0.0) + v[k_]
             del e
-        os.environ["STCN_LOOKAHEAD"] = la_saved
 
     r2, r2_roof = None, None
     if a.r2:
@@ -659,17 +726,24 @@ def main():
     torch.cuda.empty_cache()
     dv = None
     if (a.davis_val or a.workload == "davis-val") and real is None and K_OBJ == 1:
-        dv = davis_val_leg(prop, fuse, a, H, W, rank, world, local, streams, barrier)
+        dv = davis_val_leg(prop, fuse, a, H, W, rank, world, local, streams, barrier, eo_main)
 
     # Extra leg: BASELINE config 3 at its stated size - one multi-object engine (k objects through the scribble /
     # (k+1)-channel path, the only multi-object path of the reference: inference_core.py:220-233), mem_freq = 1 (every
     # frame enters the bank: full-length memory, bank rows up to T * 1620), T = 104 (the longest clip, download_data.py:42).
     cfg3 = None
     if a.config3 and world == 1 and real is None:
-        cfg3 = config3_leg(prop, fuse, a.config3_frames, H, W, a.config3_objects)
+        # the multi-object weight recipe (synth.RECIPES[2]): same architecture and kernel launches, weights under which the
+        # decoder separates several objects - the parity statement then covers (almost) every pixel
+        prop3, fuse3 = PropagationNetwork(), FusionNet()
+        psd3, fsd3 = synth.recipe_state_dict(prop3, 2), synth.recipe_state_dict(fuse3, 2)
+        prop3.load_state_dict(psd3)
+        fuse3.load_state_dict(fsd3)
+        cfg3 = config3_leg(prop3, fuse3, a.config3_frames, H, W, a.config3_objects)
         if a.config3_oracle_frames > 1:
-            cfg3["parity_vs_cpu_oracle"] = config3_parity(prop, fuse, psd, fsd, a.config3_oracle_frames, H, W, a.config3_objects)
+            cfg3["parity_vs_cpu_oracle"] = config3_parity(prop3, fuse3, psd3, fsd3, a.config3_oracle_frames, H, W, a.config3_objects)
             cfg3["mask_iou_vs_cpu_oracle"] = cfg3["parity_vs_cpu_oracle"]["mask_iou_vs_cpu_oracle"]
+        del prop3, fuse3
     mr_roof = memread_roofline(a.config3_objects) if (a.memread_roofline and world == 1) else None
 
     # whole-job numbers: max time over ranks, frames summed over ranks
@@ -700,7 +774,7 @@ def main():
                                    f"STCN propagate: fresh engine, interact(mask,0), T={T} frames/video, "
                                    f"mem_freq={a.mem_freq}, top_k=50; one video per step per GPU",
                        "frames_per_step": T - 1, "videos_per_gpu": n_uniform, "sharding": f"videos x{world}", "streams_per_gpu": S,
-                       "key_lookahead": int(os.environ["STCN_LOOKAHEAD"]),
+                       "key_lookahead": la_main,
                        "clips": f"{S * per_lane} distinct synthetic clips (one per pooled engine)",
                        "weights": "model_weights/mivos/stcn.pth + fusion.pth" if real is not None else "synthetic recipe seed 0 (no checkpoints offline)"},
             "ms_per_frame": 1e3 * dt_all / (frames_all / world),
@@ -773,7 +847,7 @@ def main():
                                            "what": "conv launches under 19.7 FLOP/B of algorithmic intensity (1x1 channel expansions, stems)"}}
             # HBM-side bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate runs)
             try:
-                pmc_file = [f for f in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
+                pmc_file = [f for f in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
                 pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
                 out["roofline"]["traffic"] = pmc["conv_gemm_traffic_bytes_per_launch"]
                 out["roofline"]["traffic_source"] = (f"profiles/{pmc_file}: a committed capture, NOT measured by this run (rocprofv3 --pmc passes of this "
@@ -781,6 +855,14 @@ def main():
                                                      f"{pmc.get('commit', 'unknown')}: {pmc.get('captured', 'round 2')})")
             except (OSError, IndexError):
                 pass
+            # the whole FRAME against the matrix peak: FLOP the matrix cores executed in every class (conv GEMMs as executed -
+            # Winograd counted with its reduced multiplies -, memory-read affinity + read-out, Cout = 1 convs) over ALL kernel time
+            # of the leg (transforms, reduces, elementwise, gathers included).  `frac` above is pipe occupancy inside the GEMM
+            # launches; this is what the frame as a whole makes of the chip
+            exec_all = sum(prof[c]["exec_flops"] if c in ("conv", "fusion_conv") else prof[c]["flops"] for c in prof)
+            out["roofline"]["frame_executed_frac"] = exec_all / (tot_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS
+            out["roofline"]["frame_executed_tflops"] = exec_all / (tot_ms * 1e-3) / 1e12
+            out["roofline"]["frame_kernel_ms"] = tot_ms / roof_frames
             out["roofline"]["algorithmic_bytes_per_launch"] = conv["bytes"] / max(conv["launches"], 1)
             out["roofline"]["leg"] = f"{max(1, a.roof_steps)} video(s), 1 stream, HIP events per launch"
             out["device_busy_frac_roofline_leg"] = tot_ms * 1e-3 / t_roof
@@ -795,7 +877,11 @@ def main():
             out["roofline_memread"] = mr_roof
         if world == 1 and a.cpu_frames > 1:
             out["cpu_baseline"], sample = cpu_baseline(psd, fsd, H, W, a.cpu_frames, a.mem_freq)
-            out["parity_vs_cpu_oracle"] = parity_vs_oracle(prop, fuse, sample, a.mem_freq)
+            out["parity_vs_cpu_oracle"] = parity_vs_oracle(prop, fuse, sample, a.mem_freq, eo_main)
+            if a.parity_long_frames > 1 and real is None:
+                out["parity_long_clip"] = long_clip_parity(prop, fuse, psd, fsd, H, W, a.parity_long_frames, a.mem_freq, eo_main)
+            if a.parity_session_rounds > 0 and real is None:
+                out["parity_session"] = session_parity(prop, fuse, psd, fsd, H, W, a.parity_session_frames, a.parity_session_rounds, a.mem_freq, eo_main)
         else:
             out["cpu_baseline"] = None
             out["cpu_baseline_note"] = ("the CPU oracle is timed on rank 0 at N=1 only (task contract); see the N=1 line" if world > 1

@@ -22,6 +22,11 @@ class WeightDesc(C.Structure):
     _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("ndim", C.c_int32), ("shape", C.c_int64 * 4)]
 
 
+class EngineOpts(C.Structure):
+    """stcn_engine_opts: a negative field = not given (environment variable / default)."""
+    _fields_ = [(n, C.c_int32) for n in ("lookahead", "decode_batch", "key_batch", "fuse_side")]
+
+
 class Stats(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("frames", "key_miss", "value_enc", "fused", "bank_fwd", "bank_bwd")]
 
@@ -34,12 +39,14 @@ PROTOTYPES = {
     "stcn_model_create": (_I, [_I, C.POINTER(WeightDesc), _I, C.POINTER(WeightDesc), _I, C.POINTER(_P)]),
     "stcn_model_destroy": (_I, [_P]),
     "stcn_engine_create": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, C.POINTER(_P)]),
+    "stcn_engine_create_ex": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, C.POINTER(EngineOpts), C.POINTER(_P)]),
     "stcn_engine_destroy": (_I, [_P]),
     "stcn_engine_reset": (_I, [_P]),
     "stcn_engine_clone": (_I, [_P, _P, _P, _P, C.POINTER(_P)]),
     "stcn_interact": (_I, [_P, _P, _I, _I, _I]),
     "stcn_get_stats": (_I, [_P, C.POINTER(Stats)]),
     "stcn_get_flops": (_I, [_P, C.POINTER(_D)]),
+    "stcn_last_conv_path": (C.c_char_p, []),
     "stcn_test_conv": (_I, [_P, _P, _P, _P, _P, _P] + [_I] * 11),
     "stcn_test_encode_key": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "stcn_test_encode_value": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
@@ -47,6 +54,7 @@ PROTOTYPES = {
     "stcn_bench_memory_read": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, C.POINTER(_F), C.POINTER(C.c_int32)]),
     "stcn_memread_plan": (_I, [_I, _I, C.POINTER(C.c_int32)]),
     "stcn_test_fail_at": (_I, [_I]),
+    "stcn_test_side_delay_us": (_I, [_I]),
     "stcn_test_decode": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
     "stcn_test_attention": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "stcn_test_fusion": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _I, _I, _P]),

@@ -65,8 +65,12 @@ __device__ __forceinline__ void tile_to_mn(int tile, int tiles_n, int ntile, int
 // WM x WN waves per workgroup, each owning RM x RN accumulator blocks of 32x32: workgroup tile (32 WM RM) x (32 WN RN).
 // PW: pointwise instance (1x1, stride 1, one dense source): no tap walk, no validity masks, no row decode - the set-up and
 // per-K-tile scalar code of the general instance is as long as the MFMA work of an 8-K-tile ResNet 1x1 conv.
+// STCN_PW_WAVES (build-time experiment): waves per SIMD the pointwise / plain 64x64 instances are compiled for (registers <= 512 / n)
+#ifndef STCN_PW_WAVES
+#define STCN_PW_WAVES 1
+#endif
 template <int WM, int WN, int RM, int RN, bool SMALLC, bool RELU, bool PW = false>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvP p, const int tiles_n,
+__global__ __launch_bounds__(256, (RM == 1 && RN == 1 && !SMALLC) ? STCN_PW_WAVES : 1) void conv_gemm_kernel(const ConvP p, const int tiles_n,
                                                         const int ntile, const int kt_per_split, const TileDiv td) {
     constexpr int PA = WM * RM, PB = WN * RN;          // 32-row pieces of the A / B tiles (= staging chunks per thread)
     constexpr int BM = 32 * PA, BN = 32 * PB;
@@ -590,6 +594,15 @@ void allow_big_lds(const void *kernel, size_t lds) {
     std::lock_guard<std::mutex> g(mu);
     if (done.insert({dev, kernel}).second)
         (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+// which instance conv_launch takes for this (planned) conv - reported to the tests through stcn_last_conv_path()
+const char *conv_variant_name(const ConvP &p) {
+    const bool narrow = narrow_variant(p), big = p.tile_big != 0, smallc = smallc_variant(p);
+    if (p.pointwise && !big && !narrow && !smallc) return "direct_pointwise";
+    if (big) return "direct_big";
+    if (narrow) return smallc ? "direct_narrow_smallc" : "direct_narrow";
+    return smallc ? "direct_smallc" : "direct";
 }
 
 void conv_launch(const ConvP &p, hipStream_t s, hipEvent_t *ev_gemm, hipEvent_t *ev_red) {

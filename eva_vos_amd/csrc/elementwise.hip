@@ -68,17 +68,18 @@ __global__ void maxpool_kernel(const float *__restrict__ x, float *__restrict__ 
     const int ow = (int)(r % OW); r /= OW;
     const int oh = (int)(r % OH);
     const int b = (int)(r / OH);
-    // the window only leaves the image at the top / left (H, W even): taps there are CLAMPED to the edge pixel, which is inside
-    // the window anyway - the same maximum without a branch per tap (a `continue` in front of each load made hipcc wait for
-    // every load before issuing the next: 9 serialized round trips per output)
-    const int iy0 = max(2 * oh - 1, 0), ix0 = max(2 * ow - 1, 0);
+    // taps outside the image are CLAMPED to the edge pixel, which is inside the window anyway - the same maximum without a
+    // branch per tap (a `continue` in front of each load made hipcc wait for every load before issuing the next: 9 serialized
+    // round trips per output).  With even H, W (all the engine passes) only the top / left taps can leave the image; the bottom /
+    // right clamp keeps an odd size inside the buffer (OH = H / 2 rows are produced either way)
+    const int iy0 = max(2 * oh - 1, 0), ix0 = max(2 * ow - 1, 0), iy2 = min(2 * oh + 1, H - 1), ix2 = min(2 * ow + 1, W - 1);
     const float *xb = x + (long)b * H * W * C + c4 * 4;
     f32x4 v[9];
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
-            const int iy = dy == 0 ? iy0 : 2 * oh + dy - 1, ix = dx == 0 ? ix0 : 2 * ow + dx - 1;
+            const int iy = dy == 0 ? iy0 : (dy == 2 ? iy2 : 2 * oh), ix = dx == 0 ? ix0 : (dx == 2 ? ix2 : 2 * ow);
             v[dy * 3 + dx] = *reinterpret_cast<const f32x4 *>(xb + ((long)iy * W + ix) * C);
         }
     f32x4 m = v[0];
@@ -86,6 +87,13 @@ __global__ void maxpool_kernel(const float *__restrict__ x, float *__restrict__ 
     for (int t = 1; t < 9; ++t) { m.x = fmaxf(m.x, v[t].x); m.y = fmaxf(m.y, v[t].y); m.z = fmaxf(m.z, v[t].z); m.w = fmaxf(m.w, v[t].w); }
     *reinterpret_cast<f32x4 *>(y + i * 4) = m;
 }
+// test aid: keeps a stream busy for `us` microseconds (wall_clock64: the constant 100 MHz counter)
+__global__ void spin_kernel(long ticks) {
+    const long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+void spin_launch(int us, hipStream_t s) { hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s, (long)us * 100); }
+
 void maxpool3x3s2_launch(const float *x, float *y, int B, int H, int W, int C, hipStream_t s) {
     hipLaunchKernelGGL(maxpool_kernel, dim3(nblocks((long)B * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0, s, x, y,
                        B, H, W, C);
@@ -163,10 +171,12 @@ __device__ __forceinline__ void aggregate_store(const float *p, int k, float *ag
 
 // Decoder tail (prop_net.py:27-29,192) + aggregate: logit4 -> bilinear x4 -> sigmoid -> aggregate
 __global__ void up4_sigmoid_aggregate_kernel(const float *__restrict__ logit4, int k, int h4, int w4,
-                                             float *__restrict__ agg, long stride, long obj_stride) {
+                                             float *__restrict__ agg, long stride, long obj_stride, long logit_gs, long agg_gs) {
     const int H = 4 * h4, W = 4 * w4;
     const long i = blockIdx.x * 256L + threadIdx.x;
     if (i >= (long)H * W) return;
+    logit4 += blockIdx.y * logit_gs;                     // frame blockIdx.y of a decode group
+    agg += blockIdx.y * agg_gs;
     const int oy = (int)(i / W), ox = (int)(i - (long)oy * W);
     int y0, y1, x0, x1; float fy, fx;
     bil(oy, 0.25f, h4, y0, y1, fy);
@@ -186,9 +196,9 @@ __global__ void up4_sigmoid_aggregate_kernel(const float *__restrict__ logit4, i
     aggregate_store(p, k, agg, stride, i);
 }
 void up4_sigmoid_aggregate_launch(const float *logit4, int k, int h4, int w4, float *agg, long agg_stride,
-                                  hipStream_t s, long obj_stride) {
-    hipLaunchKernelGGL(up4_sigmoid_aggregate_kernel, dim3(nblocks(16L * h4 * w4)), dim3(256), 0, s, logit4, k, h4,
-                       w4, agg, agg_stride, obj_stride ? obj_stride : (long)h4 * w4);
+                                  hipStream_t s, long obj_stride, int G, long logit_gs, long agg_gs) {
+    hipLaunchKernelGGL(up4_sigmoid_aggregate_kernel, dim3(nblocks(16L * h4 * w4), G), dim3(256), 0, s, logit4, k, h4,
+                       w4, agg, agg_stride, obj_stride ? obj_stride : (long)h4 * w4, logit_gs, agg_gs);
 }
 
 // fusion tail (inference_core.py:203-207): sigmoid(fuse_net(...)) per object -> aggregate
@@ -223,7 +233,9 @@ void argmax_launch(const float *prob, int kk, int T, long npix, uint8_t *masks, 
 }
 
 // |mk|^2 per memory row (prop_net.py:86), 16 lanes per 64-float row
-__global__ void rowsumsq_kernel(const float *__restrict__ x, int n, int C, float *__restrict__ out) {
+__global__ void rowsumsq_kernel(const float *__restrict__ x, int n, int C, float *__restrict__ out, long x_bs, long out_bs) {
+    x += blockIdx.y * x_bs;                              // batch element blockIdx.y (consecutive key-cache slots)
+    out += blockIdx.y * out_bs;
     const long gt = blockIdx.x * 256L + threadIdx.x;
     const long row = gt >> 4;
     const int sub = (int)(gt & 15);
@@ -236,8 +248,8 @@ __global__ void rowsumsq_kernel(const float *__restrict__ x, int n, int C, float
     for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
     if (row < n && sub == 0) out[row] = acc;
 }
-void rowsumsq_launch(const float *x, int n, int C, float *out, hipStream_t s) {
-    hipLaunchKernelGGL(rowsumsq_kernel, dim3(nblocks((long)n * 16)), dim3(256), 0, s, x, n, C, out);
+void rowsumsq_launch(const float *x, int n, int C, float *out, hipStream_t s, int B, long x_bs, long out_bs) {
+    hipLaunchKernelGGL(rowsumsq_kernel, dim3(nblocks((long)n * 16), B), dim3(256), 0, s, x, n, C, out, x_bs, out_bs);
 }
 
 __global__ void fill_kernel(float *p, float v, long n) {

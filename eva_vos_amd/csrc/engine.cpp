@@ -25,6 +25,17 @@ void set_error(const char *fmt, ...) {
 }
 const char *get_error() { return g_err; }
 
+Knobs Knobs::from_env() {
+    Knobs k;
+    auto geti = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
+    k.wino_min_cin = geti("STCN_WINO_MIN_CIN", k.wino_min_cin);
+    k.wino_ppw = geti("STCN_WINO_PPW", k.wino_ppw);
+    k.wino4_chunk_mb = geti("STCN_WINO4_CHUNK_MB", k.wino4_chunk_mb);
+    k.fusion_conv12 = geti("STCN_FUSION_CONV12", k.fusion_conv12) != 0;
+    k.fusion_wino = geti("STCN_FUSION_WINO", k.fusion_wino) != 0;
+    return k;
+}
+
 // ---------------------------------------------------------------------------------------------- Prof
 void Prof::reset() {
     for (int i = 0; i < STCN_K_COUNT; ++i) { flops[i] = 0; bytes[i] = 0; exec_flops[i] = 0; launches[i] = 0; }
@@ -103,7 +114,7 @@ static int upload(Model &m, const std::vector<float> &h, float **dev) {
 int make_wino(Model &m, ConvW &cw, const std::vector<float> &w) {
     static const bool on = [] { const char *e = getenv("STCN_WINOGRAD"); return !e || atoi(e) != 0; }();
     const bool fusion32 = cw.cin_p == 32 && cw.cout == 32;           // FusionNet's 32 -> 32 layers: fusion_wino_kernel (fusion_conv.hip)
-    if (!on || cw.kh != 3 || cw.kw != 3 || cw.cin_p % 32 || ((cw.cin_p < wino_min_cin() || cw.cout % 64) && !fusion32)) return STCN_OK;
+    if (!on || cw.kh != 3 || cw.kw != 3 || cw.cin_p % 32 || ((cw.cin_p < Knobs::from_env().wino_min_cin || cw.cout % 64) && !fusion32)) return STCN_OK;
     std::vector<float> u((size_t)16 * cw.cin_p * cw.cout);
     wino_transform_weights(w.data(), cw.cout, cw.cin_p, cw.Kp, u.data());
     return upload(m, u, &cw.wino_u);
@@ -286,7 +297,7 @@ struct DevPool {
     std::unordered_map<void *, std::pair<int, size_t>> live;           // buffers handed out
     size_t cached = 0;
     size_t cap() {
-        static const size_t c = [] { const char *e = getenv("STCN_POOL_GB"); return (size_t)(e ? atof(e) : 64.0) << 30; }();
+        static const size_t c = [] { const char *e = getenv("STCN_POOL_GB"); const double gb = e ? atof(e) : 64.0; return gb > 0 ? (size_t)(gb * (double)(1u << 30)) : (size_t)0; }();   // fractions count (0.5 = 512 MB)
         return c;
     }
     static size_t size_class(size_t bytes) {
@@ -305,14 +316,21 @@ hipError_t pool_malloc(void **p, size_t bytes) {
     (void)hipGetDevice(&dev);
     const size_t sc = DevPool::size_class(bytes);
     if (pl.cap() > 0) {
-        std::lock_guard<std::mutex> g(pl.mu);
-        auto it = pl.free_.find({dev, sc});
-        if (it != pl.free_.end() && !it->second.empty()) {
-            *p = it->second.back();
-            it->second.pop_back();
-            pl.cached -= sc;
-            pl.live[*p] = {dev, sc};
+        bool hit = false;
+        {
+            std::lock_guard<std::mutex> g(pl.mu);
+            auto it = pl.free_.find({dev, sc});
+            if (it != pl.free_.end() && !it->second.empty()) {
+                *p = it->second.back();
+                it->second.pop_back();
+                pl.cached -= sc;
+                pl.live[*p] = {dev, sc};
+                hit = true;
+            }
+        }
+        if (hit) {
             // STCN_POOL_POISON=1 (tests): a recycled buffer arrives full of NaNs - anything read before it is written shows up
+            // (outside the pool lock: the memset + sync would serialise the other lanes' allocations behind it)
             static const bool poison = [] { const char *e = getenv("STCN_POOL_POISON"); return e && atoi(e) != 0; }();
             if (poison) { (void)hipMemset(*p, 0xFF, sc); (void)hipStreamSynchronize(nullptr); }     // the engines' streams do not wait for the null stream
             return hipSuccess;
@@ -424,6 +442,8 @@ void Work::release() {
 // the launch class that failed - not as an anonymous error at the end of the interaction
 // fault injection for tests (stcn_test_fail_at): the n-th launch_status() call of this thread reports a failure
 static thread_local int g_fail_countdown = 0;
+static thread_local int g_fail_reserve = 0;      // tests (stcn_test_fail_at(-1)): the next up-front bank reservation of this thread fails
+static int g_side_delay_us = 0;          // tests (stcn_test_side_delay_us): every offloaded FusionNet group starts this much later
 void inject_failure_after(int n) { g_fail_countdown = n; }
 int launch_status(const char *what) {
     if (g_fail_countdown > 0 && --g_fail_countdown == 0) {
@@ -436,6 +456,10 @@ int launch_status(const char *what) {
     set_error("launch of '%s' failed: %s", what, hipGetErrorString(er));
     return STCN_E_HIP;
 }
+
+static thread_local char g_conv_path[96] = "";
+const char *last_conv_path() { return g_conv_path; }
+void set_conv_path(const char *s) { snprintf(g_conv_path, sizeof(g_conv_path), "%s", s); }
 
 int run_conv(const Model &m, Work &w, hipStream_t s, const char *name, const float *x0, int c0, long bs0,
              const float *x1, int c1, long bs1, int B, int H, int W, int stride, float *y, long y_bs,
@@ -471,6 +495,7 @@ int run_conv(const Model &m, Work &w, hipStream_t s, const char *name, const flo
     p.affine_out = (y_bs == 0 || y_bs == (long)p.OH * p.OW * p.N) && (!res || (res_bs == (long)p.OH * p.OW * p.N && !res_bmod)) &&
                    ((long)p.M + 128) * p.N * 4 < (1L << 32);
     p.partial = w.splitk;
+    p.kn = w.kn;
     const bool fus = force_splitk <= 0 && fusion_conv_eligible(p);      // FusionNet shapes: the dedicated kernel
     if (!fus) conv_plan(p, force_splitk, w.splitk_floats);
     const double fl = 2.0 * p.M * p.N * (double)(cw.kh * cw.kw * cw.cin);
@@ -515,6 +540,12 @@ int run_conv(const Model &m, Work &w, hipStream_t s, const char *name, const flo
             er = w.prof->attach(STCN_K_CONV_REDUCE);
         }
     }
+    // which kernel family takes this conv (tests assert it per case: a shape that silently fell back to another instance would
+    // still pass a numerical comparison)
+    if (fus) snprintf(g_conv_path, sizeof(g_conv_path), "%s", fusion_conv_winograd(p) ? "fusion_wino" : "fusion_direct");
+    else if (wino4) snprintf(g_conv_path, sizeof(g_conv_path), "wino4 chunks=%d%s", wino4_chunks(p, w.splitk_floats), wino4_tail_split(p, w.splitk_floats) ? " +tail" : "");
+    else if (wino) snprintf(g_conv_path, sizeof(g_conv_path), "wino2 ppw=%d splitk=%d", p.kn.wino_ppw == 1 || p.kn.wino_ppw == 2 ? p.kn.wino_ppw : (p.Cin <= 512 ? 1 : 2), wino_plan_splitk(p, w.splitk_floats));
+    else snprintf(g_conv_path, sizeof(g_conv_path), "%s%s splitk=%d", conv_variant_name(p), p.rem_split > 1 ? " +tail" : "", p.splitk);
     if (fus) fusion_conv_launch(p, s, eg);
     else if (wino4) wino4_launch(p, w.wino_v, w.splitk_floats, s, ei ? ei4 : nullptr, eg ? eg4 : nullptr, er);
     else if (wino) wino_launch(p, w.wino_v, w.splitk_floats, s, ei, eg, er);
@@ -580,7 +611,7 @@ int encode_key(const Model &m, Work &w, hipStream_t s, const float *img4, const 
         RC(cv("key_proj.key_proj", o.f16, 1024, f16_bs, d.h16, d.w16, 1, o.k16, out_bs, nullptr, 0, 0, 0));
         if (o.msq) {
             Scope sc(w.prof, STCN_K_ELEMWISE, s);
-            for (int b = 0; b < B; ++b) rowsumsq_launch(o.k16 + b * out_bs, d.hw16, 64, o.msq + b * out_bs, s);
+            rowsumsq_launch(o.k16, d.hw16, 64, o.msq, s, B, out_bs, out_bs);       // one launch for the B frames of the pass
         }
     }
     if (o.f16_thin) RC(cv("key_comp", o.f16, 1024, f16_bs, d.h16, d.w16, 1, o.f16_thin, out_bs, nullptr, 0, 0, 0));
@@ -699,10 +730,8 @@ int decode(const Model &m, Work &w, hipStream_t s, const float *readout, const f
     }
     {
         Scope sc(w.prof, STCN_K_ELEMWISE, s);
-        if (G > 1)                               // frame g: its k objects are G planes apart; agg [G][k+1][npix]
-            for (int g = 0; g < G; ++g)
-                up4_sigmoid_aggregate_launch(w.logit4 + (size_t)g * d.hw4, k, d.h4, d.w4, agg + (size_t)g * (k + 1) * agg_stride, agg_stride, s,
-                                             (long)G * d.hw4);
+        if (G > 1)                               // frame g: its k objects are G planes apart; agg [G][k+1][npix]; one launch for the group
+            up4_sigmoid_aggregate_launch(w.logit4, k, d.h4, d.w4, agg, agg_stride, s, (long)G * d.hw4, G, (long)d.hw4, (long)(k + 1) * agg_stride);
         else
             up4_sigmoid_aggregate_launch(w.logit4, k, d.h4, d.w4, agg, agg_stride, s);
     }
@@ -852,18 +881,19 @@ static int engine_alloc_common(stcn_engine *e) {
     RC(eng_alloc(e, (void **)&e->mask_pad, (size_t)(e->k + 1) * d.npix * 4));
     RC(eng_alloc(e, (void **)&e->pos, (size_t)(e->k + 1) * d.npix * 4));
     RC(eng_alloc(e, (void **)&e->neg, (size_t)(e->k + 1) * d.npix * 4));
-    const char *la = getenv("STCN_LOOKAHEAD");
-    const int la_env = la ? atoi(la) : 2;                 // 0: no side stream at all (profiling legs: solo launches only)
+    // engine tunables: an explicit option (stcn_engine_create_ex) wins, else the environment variable - read HERE, once per
+    // engine - else the default.  The resolved values are kept for clones
+    auto opt = [](int32_t &field, const char *env, int dflt) { if (field < 0) { const char *v = getenv(env); field = v ? atoi(v) : dflt; } return (int)field; };
+    const int la_env = opt(e->opts.lookahead, "STCN_LOOKAHEAD", 2);       // 0: no side stream at all (profiling legs: solo launches only)
     e->lookahead = la_env;
     if (e->T > e->n_slots) e->lookahead = 0;
-    const char *gb = getenv("STCN_DECODE_BATCH");
-    e->group = gb ? atoi(gb) : 8;
+    e->group = opt(e->opts.decode_batch, "STCN_DECODE_BATCH", 8);
     if (e->group > e->mem_freq) e->group = e->mem_freq;      // a group ends at the next bank insertion
     if (e->group < 1) e->group = 1;
     if (e->group > 8) e->group = 8;
     while (e->group > 1 && e->group * e->k > 16) --e->group;   // objects x frames per decoder pass (workspace ~ 0.1 GB each)
-    const char *kb = getenv("STCN_KEY_BATCH");
-    e->key_batch = kb ? atoi(kb) : (e->group > 4 ? e->group : 4);   // a decode group is key-encoded in one pass
+    e->key_batch = opt(e->opts.key_batch, "STCN_KEY_BATCH", 0);
+    if (e->key_batch <= 0) e->key_batch = e->group > 4 ? e->group : 4;   // a decode group is key-encoded in one pass
     if (e->key_batch < 1) e->key_batch = 1;
     if (e->key_batch > 8) e->key_batch = 8;
     RC(e->work.init(d.nh, d.nw, e->k, e->lookahead > 0 ? 1 : e->key_batch, e->group));
@@ -872,8 +902,7 @@ static int engine_alloc_common(stcn_engine *e) {
     // next frames then runs on a side stream concurrently with the memory-read / decoder chain.
     // The side stream also runs FusionNet in rounds >= 2 (fuse_side), which does not depend on the cache policy: clips longer
     // than the key cache (MOSE) keep it for that alone.
-    const char *fs = getenv("STCN_FUSE_SIDE");
-    e->fuse_side = la_env > 0 && e->model->has_fuse && (!fs || atoi(fs) != 0);
+    e->fuse_side = la_env > 0 && e->model->has_fuse && opt(e->opts.fuse_side, "STCN_FUSE_SIDE", 1) != 0;
     if (e->lookahead > 0 || e->fuse_side) {
         HIPCHK(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
         RC(e->work_side.init(d.nh, d.nw, e->k, e->lookahead > 0 ? e->key_batch : 1));      // k objects: it also runs FusionNet
@@ -893,6 +922,11 @@ static int engine_alloc_common(stcn_engine *e) {
 
 int stcn_engine_create(const stcn_model *m, int T, int H, int W, int k, int mem_freq, void *stream,
                        const float *images_dev, float *prob_dev, uint8_t *masks_dev, stcn_engine **out) {
+    return stcn_engine_create_ex(m, T, H, W, k, mem_freq, stream, images_dev, prob_dev, masks_dev, nullptr, out);
+}
+
+int stcn_engine_create_ex(const stcn_model *m, int T, int H, int W, int k, int mem_freq, void *stream,
+                          const float *images_dev, float *prob_dev, uint8_t *masks_dev, const stcn_engine_opts *opts, stcn_engine **out) {
     if (!m || !images_dev || !prob_dev || !masks_dev || !out) { set_error("stcn_engine_create: null arguments"); return STCN_E_INVALID; }
     if (T < 1 || H < 16 || W < 16 || k < 1 || k > 8 || mem_freq < 1) {
         set_error("stcn_engine_create: bad shape T=%d H=%d W=%d k=%d mem_freq=%d (1<=k<=8)", T, H, W, k, mem_freq);
@@ -901,6 +935,7 @@ int stcn_engine_create(const stcn_model *m, int T, int H, int W, int k, int mem_
     HIPCHK(hipSetDevice(m->m.device));
     stcn_engine *e = new stcn_engine();
     e->model = &m->m; e->stream = (hipStream_t)stream;
+    if (opts) e->opts = *opts;
     e->T = T; e->H = H; e->W = W; e->k = k; e->mem_freq = mem_freq;
     const int nh = (H + 15) / 16 * 16, nw = (W + 15) / 16 * 16;
     e->lh = (nh - H) / 2; e->uh = nh - H - e->lh; e->lw = (nw - W) / 2; e->uw = nw - W - e->lw;
@@ -969,6 +1004,7 @@ int stcn_engine_clone(const stcn_engine *src, float *prob_dev, uint8_t *masks_de
     e->lw = src->lw; e->uw = src->uw; e->lh = src->lh; e->uh = src->uh; e->d = src->d;
     e->prob = prob_dev; e->masks = masks_dev;
     e->images4 = src->images4; e->images_owner = src->images_owner;      // read-only: shared, not copied
+    e->opts = src->opts;                                                 // the source's resolved tunables, not today's environment
     int rc = engine_alloc_common(e);
     if (!rc) rc = bank_reserve(e, src->bank_cap);
     if (!rc) rc = clone_state(e, src);
@@ -1177,10 +1213,14 @@ static int do_pass(stcn_engine *e, int idx, bool forward) {
             return launch_status("memory read");
         };
         const bool off = offload && (batched || G == 1);           // unbatched groups of several frames reuse one agg slot: fused in line
-        float *const aggbuf = off && e->agg_buf ? w.agg_alt : w.agg;
-        if (off && e->fuse_pending[e->agg_buf]) {                  // the side stream may still read this buffer (two groups ago)
-            HIPCHK(hipStreamWaitEvent(e->stream, e->ev_fuse[e->agg_buf], 0));
-            e->fuse_pending[e->agg_buf] = 0;
+        // the aggregate buffer this group decodes into: offloaded groups alternate, everything else uses buffer 0.  WHOEVER writes
+        // a buffer first waits for the side stream's FusionNet of the group that used it last (two offloaded groups ago - or,
+        // for a group that is not offloaded: the last offloaded group of the previous sweep / an earlier offloaded group of this one)
+        const int bi = off ? e->agg_buf : 0;
+        float *const aggbuf = bi ? w.agg_alt : w.agg;
+        if (e->fuse_pending[bi]) {
+            HIPCHK(hipStreamWaitEvent(e->stream, e->ev_fuse[bi], 0));
+            e->fuse_pending[bi] = 0;
         }
         // agg of the frame at sweep position g lives at aggbuf + pos(g) * agg_fs
         auto pos = [&](int g) { return batched ? (ti + g * step) - t_lo : 0; };
@@ -1229,6 +1269,7 @@ static int do_pass(stcn_engine *e, int idx, bool forward) {
                 if (off && g == 0) {                           // (groups decode in one pass: every agg of the group is final here)
                     HIPCHK(hipEventRecord(e->ev_dec[e->agg_buf], e->stream));
                     HIPCHK(hipStreamWaitEvent(e->side, e->ev_dec[e->agg_buf], 0));
+                    if (g_side_delay_us > 0) spin_launch(g_side_delay_us, e->side);      // tests: a slow side stream (stcn_test_side_delay_us)
                 }
                 {
                     Scope sc(&e->prof, STCN_K_ATTENTION, fs, 2.0 * d.hw16 * d.hw16 * 64);
@@ -1264,14 +1305,6 @@ static int do_pass(stcn_engine *e, int idx, bool forward) {
 static int interact_run(stcn_engine *e, const float *mask_dev, int mask_channels, int idx, int scribble) {
     const int kk = e->k + 1;
     const Dims &d = e->d;
-    // reserve first: everything that can fail for lack of memory happens before the first mutation.  The bank must hold
-    // the certain slots (+1) and the temporary slots of the longer of the two sweeps
-    {
-        int lo = -1, hi = e->T;
-        for (int t : e->interacted) { if (t < idx && t > lo) lo = t; if (t > idx && t < hi) hi = t; }
-        const int span = std::max(hi - idx - 1, idx - lo - 1);
-        RC(bank_reserve(e, span / e->mem_freq + 1 + e->n_certain + 1));
-    }
     e->interacted.insert(idx);
     {
         Scope sc(&e->prof, STCN_K_ELEMWISE, e->stream);
@@ -1319,6 +1352,18 @@ int stcn_interact(stcn_engine *e, const float *mask_dev, int mask_channels, int 
     }
     HIPCHK(hipSetDevice(e->model->device));
     bank_collect_retired(e, false);
+    // reserve first: everything that can fail for lack of memory happens before the first mutation.  The bank must hold the
+    // certain slots (+1) and the temporary slots of the longer of the two sweeps.  A failure HERE has touched nothing (bank_reserve
+    // frees what it allocated and keeps the old generation): the error is returned and the engine stays usable - the caller may
+    // release memory (stcn_pool_release) and call again; only failures past this point enter the failed state
+    {
+        int lo = -1, hi = e->T;
+        for (int t : e->interacted) { if (t < idx && t > lo) lo = t; if (t > idx && t < hi) hi = t; }
+        const int span = std::max(hi - idx - 1, idx - lo - 1);
+        const int rc0 = g_fail_reserve ? (g_fail_reserve = 0, set_error("bank_reserve: injected fault (stcn_test_fail_at(-1))"), STCN_E_HIP)
+                                       : bank_reserve(e, span / e->mem_freq + 1 + e->n_certain + 1);
+        if (rc0) return rc0;
+    }
     e->stats = stcn_stats{};
     e->prof.reset();
     const bool was_interacted = e->interacted.count(idx) != 0;
@@ -1342,8 +1387,19 @@ int stcn_interact(stcn_engine *e, const float *mask_dev, int mask_channels, int 
 // returns the device memory parked in the engine-buffer pool (freed engines' workspaces) to the driver
 int stcn_pool_release(void) { pool_release(); return STCN_OK; }
 
+// the kernel family the calling thread's last convolution ran as (stcn_test_conv / the engine's last conv)
+const char *stcn_last_conv_path(void) { return stcn::last_conv_path(); }
+
+// test hook: delays the side stream by `us` microseconds in front of every offloaded FusionNet group (0: off).  Makes the
+// orderings between the two streams that are only enforced by events observable: a missing wait shows up as a wrong result
+int stcn_test_side_delay_us(int us) { g_side_delay_us = us < 0 ? 0 : us; return STCN_OK; }
+
 // test hook: the n-th launch-status check of the calling thread (counted from now) reports an injected failure
-int stcn_test_fail_at(int n) { inject_failure_after(n); return STCN_OK; }
+int stcn_test_fail_at(int n) {
+    if (n < 0) { g_fail_reserve = 1; return STCN_OK; }       // -1: the next stcn_interact fails in its up-front reservation (nothing touched)
+    inject_failure_after(n);
+    return STCN_OK;
+}
 
 int stcn_get_stats(const stcn_engine *e, stcn_stats *out) {
     if (!e || !out) return STCN_E_INVALID;

@@ -106,6 +106,7 @@ struct Work {
     float *qk = nullptr;                // [group][hw16][64] queries of a decode group
     float *vin = nullptr;               // value-encoder packed input [k][npix][8]
     Prof *prof = nullptr;
+    Knobs kn = Knobs::from_env();       // launch-level tunables, read once when the workspace is made
     int conv_cls = STCN_K_CONV;         // accounting class of the conv GEMMs launched through this workspace (fusion_logit switches it)
     std::vector<void *> allocs;
     int init(int nh, int nw, int k, int key_batch = 1, int group = 1);   // group: frames decoded per pass (k == 1)
@@ -115,7 +116,9 @@ struct Work {
 // ---- stages (enqueue only) -----------------------------------------------------------------
 struct KeyOut { float *k16, *msq, *f16_thin, *f16, *s8, *s4, *f8_copy, *f4_copy, *dthin = nullptr, *cthin = nullptr; };
 void inject_failure_after(int n);        // tests: the n-th launch_status() of this thread fails
-int launch_status(const char *what);     // STCN_OK, or STCN_E_HIP with the failing launch class in the error string
+int launch_status(const char *what);
+const char *last_conv_path();            // kernel family of this thread's last run_conv ("wino4 chunks=2", "direct_pointwise splitk=1", ...)
+void set_conv_path(const char *s);     // STCN_OK, or STCN_E_HIP with the failing launch class in the error string
 int run_conv(const Model &m, Work &w, hipStream_t s, const char *name, const float *x0, int c0, long bs0,
              const float *x1, int c1, long bs1, int B, int H, int W, int stride, float *y, long y_bs,
              const float *res, long res_bs, int relu_in, int relu_out, int force_splitk = 0, int res_bmod = 0);
@@ -143,6 +146,7 @@ struct stcn_engine {
     const stcn::Model *model = nullptr;
     hipStream_t stream = nullptr;
     int T = 0, H = 0, W = 0, k = 0, mem_freq = 5;
+    stcn_engine_opts opts{-1, -1, -1, -1};   // tunables: as given to stcn_engine_create_ex, then resolved (environment / defaults) at create
     int lw = 0, uw = 0, lh = 0, uh = 0;
     stcn::Dims d{};
     float *images4 = nullptr;          // [T][nh][nw][4]; immutable after create, shared with clones

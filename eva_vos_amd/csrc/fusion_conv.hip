@@ -317,22 +317,12 @@ __global__ __launch_bounds__(256, 2) void fusion_wino_kernel(const float *__rest
 
 // conv1 (9 -> 12 channels in HBM, 16 per tap here: a quarter of its MFMAs multiply zeros) measured 53 us on this kernel, 49 us
 // on the generic one: off by default (STCN_FUSION_CONV12=1 switches it on; the instance stays tested)
-static bool fusion_conv12() {
-    const char *e = getenv("STCN_FUSION_CONV12");
-    return e && atoi(e) != 0;
-}
-
-static bool fusion_wino() {
-    const char *e = getenv("STCN_FUSION_WINO");                              // read per launch: tests run both kernels
-    return !e || atoi(e) != 0;
-}
-
-bool fusion_conv_winograd(const ConvP &p) { return (p.Cin == 32 || p.Cin == 12) && p.wino_u && fusion_wino(); }
+bool fusion_conv_winograd(const ConvP &p) { return (p.Cin == 32 || p.Cin == 12) && p.wino_u && p.kn.fusion_wino; }
 
 bool fusion_conv_eligible(const ConvP &p) {
     static const bool on = [] { const char *e = getenv("STCN_FUSION_CONV"); return !e || atoi(e) != 0; }();
     return on && p.N == 32 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.B == 1 && !p.x1 && !p.relu_in &&
-           (p.Cin == 32 || (p.Cin == 12 && (fusion_conv12() || fusion_conv_winograd(p)))) &&
+           (p.Cin == 32 || (p.Cin == 12 && (p.kn.fusion_conv12 || fusion_conv_winograd(p)))) &&
            p.K == 9 * p.Cin && (p.y_bs == 0) && (!p.res || !p.res_bmod) && p.bias;
 }
 

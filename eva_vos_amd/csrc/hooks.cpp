@@ -50,7 +50,11 @@ int stcn_test_conv(void *stream, const float *x, const float *wgt, const float *
         RC(make_wino(m, cw, hw));
         RC(make_wino_fusion12(m, cw, hw));
         if (flags & 4) { RC(make_wino4(m, cw, hw)); m.wino4_min_wg = 0; }        // flags bit 2: as a decoder layer (F(4x4,3x3))
-        w.wino_v_floats = (size_t)16 * Cin * (((size_t)B * ((OH + 1) / 2) * ((OW + 1) / 2) + 63) / 64 * 64);
+        // V of either Winograd form: 16 positions x tiles of 2x2 padded to 64, or 36 positions x tiles of 4x4 padded to 128 (for a
+        // handful of tiles the padded F(4x4) workspace is the larger one - sized for F(2x2) alone such a case fell back silently)
+        const size_t v2 = (size_t)16 * Cin * (((size_t)B * ((OH + 1) / 2) * ((OW + 1) / 2) + 63) / 64 * 64);
+        const size_t v4 = (size_t)36 * Cin * (((size_t)B * ((OH + 3) / 4) * ((OW + 3) / 4) + 127) / 128 * 128);
+        w.wino_v_floats = v2 > v4 ? v2 : v4;
         RC(wv.alloc(w.wino_v_floats));
         w.wino_v = wv.p;
     }
@@ -63,6 +67,7 @@ int stcn_test_conv(void *stream, const float *x, const float *wgt, const float *
         float b0 = 0.f;
         if (bias) HIPCHK(hipMemcpy(&b0, bias, 4, hipMemcpyDeviceToHost));
         conv_n1_launch(x, wpad.p, b0, y, B, H, W, Cin, KH, flags & 1, s);
+        set_conv_path("n1");
     } else {
         RC(run_conv(m, w, s, "t", x, Cin, (long)H * W * Cin, nullptr, 0, 0, B, H, W, stride, y, 0, res, (long)OH * OW * Cout,
                     flags & 1, (flags >> 1) & 1, splitk));
@@ -102,7 +107,11 @@ int stcn_bench_conv(void *stream, int B, int H, int W, int Cin, int Cout, int KH
         RC(make_wino(m, cw, h));
         RC(make_wino_fusion12(m, cw, h));
         if (getenv("STCN_BENCH_CONV_F4")) RC(make_wino4(m, cw, h));              // time the layer as a decoder layer
-        w.wino_v_floats = (size_t)16 * Cin * (((size_t)B * ((OH + 1) / 2) * ((OW + 1) / 2) + 63) / 64 * 64);
+        // V of either Winograd form: 16 positions x tiles of 2x2 padded to 64, or 36 positions x tiles of 4x4 padded to 128 (for a
+        // handful of tiles the padded F(4x4) workspace is the larger one - sized for F(2x2) alone such a case fell back silently)
+        const size_t v2 = (size_t)16 * Cin * (((size_t)B * ((OH + 1) / 2) * ((OW + 1) / 2) + 63) / 64 * 64);
+        const size_t v4 = (size_t)36 * Cin * (((size_t)B * ((OH + 3) / 4) * ((OW + 3) / 4) + 127) / 128 * 128);
+        w.wino_v_floats = v2 > v4 ? v2 : v4;
         RC(wv.alloc(w.wino_v_floats));
         w.wino_v = wv.p;
     }

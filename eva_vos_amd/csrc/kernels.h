@@ -28,6 +28,18 @@ __device__ __forceinline__ int fastdiv(int x, const FastDiv f) {
 }
 #endif
 
+// ---------------------------------------------------------------- launch-level tunables
+// Read from the environment ONCE per workspace (= once per engine, once per stage-hook call) by Knobs::from_env() and carried in
+// every ConvP - never read per launch: a driver may change os.environ between legs while host threads of other lanes launch.
+struct Knobs {
+    int wino_min_cin = 128;     // STCN_WINO_MIN_CIN: fewest input channels for which a stride-1 3x3 conv takes the F(2x2) path
+    int wino_ppw = 0;           // STCN_WINO_PPW: 1 / 2 pins the F(2x2) GEMM instance (positions per wave), 0 = by shape
+    int wino4_chunk_mb = 160;   // STCN_WINO4_CHUNK_MB: V bytes per slice of a chunked F(4x4) launch (0: unchunked)
+    int fusion_conv12 = 0;      // STCN_FUSION_CONV12: FusionNet conv1 on the direct FusionNet kernel
+    int fusion_wino = 1;        // STCN_FUSION_WINO: FusionNet convs as Winograd F(2x2) inside the workgroup
+    static Knobs from_env();
+};
+
 // ---------------------------------------------------------------- implicit-GEMM convolution
 // Activations NHWC fp32.  Input = channel-concat of up to two sources (second may be batch-broadcast).
 struct ConvP {
@@ -63,6 +75,7 @@ struct ConvP {
     int affine_out;         // y (and res, if any) are dense [M][N]: element (m, n) at (m * N + n) * 4 bytes, < 4 GiB
     int tile_big;           // 1 = 128x128 workgroup tiles (fp32 kernel)
     int panel;              // > 0: tiles are walked in panels of this many n-tiles (fp32 kernel)
+    Knobs kn;               // the workspace's snapshot of the launch-level tunables
 };
 // fills the launch plan of p (tile variant, split-K or tail balancing); force_splitk > 0 pins a plain split-K;
 // workspace_floats = capacity of p.partial
@@ -70,11 +83,11 @@ void conv_plan(ConvP &p, int force_splitk, size_t workspace_floats);
 // ev_gemm / ev_red: optional {start, stop} event pairs attached to the GEMM / reduce dispatches themselves
 // (hipExtLaunchKernelGGL: kernel begin/end timestamps, no extra barrier packets)
 void conv_launch(const ConvP &p, hipStream_t s, hipEvent_t *ev_gemm = nullptr, hipEvent_t *ev_red = nullptr);
+const char *conv_variant_name(const ConvP &p);     // the conv_gemm_kernel instance a planned conv takes ("direct", "direct_pointwise", ...)
 // split-K tail of a conv whose slabs p.partial [p.splitk][M][N] are filled: sum + bias / residual / ReLU -> y
 void conv_reduce_launch(const ConvP &p, hipStream_t s, hipEvent_t *ev_red = nullptr);
 // Winograd F(2x2,3x3) path (winograd.hip): V workspace floats this conv needs, or 0 when it is not eligible
 size_t wino_workspace_floats(const ConvP &p);
-int wino_min_cin();
 void wino_launch(const ConvP &p, float *V, size_t slab_floats, hipStream_t s, hipEvent_t *ev_in = nullptr, hipEvent_t *ev_gemm = nullptr,
                  hipEvent_t *ev_red = nullptr);
 int wino_plan_splitk(const ConvP &p, size_t slab_floats);
@@ -114,16 +127,19 @@ void upsample2x_add_launch(const float *x, const float *skip, float *u, int B, i
                            hipStream_t s, long skip_bs = 0, int skip_bmod = 0);
 // logit4 [k,h4*w4] -> bilinear x4 -> sigmoid -> aggregate_wbg -> agg [k+1][nh*nw] (row stride agg_stride)
 // obj_stride: floats between the logit planes of consecutive objects (0 = h4*w4)
+// G > 1: G frames in one launch - frame g reads logit4 + g * logit_gs and writes agg + g * agg_gs
 void up4_sigmoid_aggregate_launch(const float *logit4, int k, int h4, int w4, float *agg,
-                                  long agg_stride, hipStream_t s, long obj_stride = 0);
+                                  long agg_stride, hipStream_t s, long obj_stride = 0, int G = 1, long logit_gs = 0, long agg_gs = 0);
 // logits [k,npix] -> sigmoid -> aggregate -> agg rows (fusion output)
 void sigmoid_aggregate_launch(const float *logit, int k, long npix, float *agg, long agg_stride,
                               hipStream_t s);
 // masks[t] = argmax over rows of prob [(k+1), T, npix] for all t (first max wins)
 void argmax_launch(const float *prob, int kk, int T, long npix, uint8_t *masks, hipStream_t s);
 // rows [n, C] -> msq[n] = sum_c x^2
-void rowsumsq_launch(const float *x, int n, int C, float *out, hipStream_t s);
+// B > 1: B batch elements in one launch (element b at x + b * x_bs -> out + b * out_bs)
+void rowsumsq_launch(const float *x, int n, int C, float *out, hipStream_t s, int B = 1, long x_bs = 0, long out_bs = 0);
 void fill_launch(float *p, float v, long n, hipStream_t s);
+void spin_launch(int us, hipStream_t s);        // test aid: one wave that keeps stream s busy for `us` microseconds
 void copy_rows_launch(const float *src, long src_stride, float *dst, long dst_stride, int rows, long n,
                       hipStream_t s);
 // interaction mask handling (inference_core.py:220-226): pads mask [mc,H,W] into [mc,nh,nw] planes,

@@ -300,16 +300,10 @@ static bool wino_enabled() {
     return on;
 }
 
-// fewest input channels worth the transforms (STCN_WINO_MIN_CIN)
-int wino_min_cin() {
-    const char *e = getenv("STCN_WINO_MIN_CIN");          // read per call: the unit tests run the 64-channel path
-    return e ? atoi(e) : 128;
-}
-
 // floats of V workspace the Winograd path needs for this conv (0: not eligible)
 size_t wino_workspace_floats(const ConvP &p) {
     if (!wino_enabled() || !p.wino_u || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.x1) return 0;
-    if (p.Cin % 32 || p.Cin < wino_min_cin() || p.N % WN || p.bs0 == 0) return 0;
+    if (p.Cin % 32 || p.Cin < p.kn.wino_min_cin || p.N % WN || p.bs0 == 0) return 0;
     const long Mt = (long)p.B * ((p.OH + 1) / 2) * ((p.OW + 1) / 2);
     const long Mt_pad = (Mt + WT - 1) / WT * WT;
     // 64-channel layers (K = 8 k-blocks; opt-in: STCN_WINO_MIN_CIN=64): the transforms and the epilogue outweigh the MFMA saving
@@ -377,8 +371,7 @@ void wino_launch(const ConvP &p, float *V, size_t slab_floats, hipStream_t s, hi
     const size_t lds = (size_t)16 * WT * 32 * sizeof(float);
     // 16 waves x 1 position (4 waves per SIMD) feed the matrix pipe a little better on the short-K layers (+1.5-3 % up to 512
     // input channels); with 1024+ channels the 8-wave form with its deeper per-wave prefetch is as good or better
-    const char *ppw_s = getenv("STCN_WINO_PPW");          // read per launch: tests run every shape under both instances
-    const int ppw_env = ppw_s ? atoi(ppw_s) : 0;
+    const int ppw_env = p.kn.wino_ppw;                    // tests run every shape under both instances
     const int ppw = ppw_env == 1 || ppw_env == 2 ? ppw_env : (p.Cin <= 512 ? 1 : 2);
     if (ppw == 1) {
         allow_big_lds(reinterpret_cast<const void *>(&wino_gemm_kernel<1>), lds);

@@ -499,8 +499,7 @@ static W4Plan wino4_plan(const ConvP &p, size_t slab_floats) {
     // then see HBM latency: 97-99 us per round of workgroups instead of 89 (measured at 75 / 151 / 302 / 604 MB of V).  Transform
     // and GEMM alternate over slices of whole rounds whose V stays under ~160 MB.
     pl.chunks = 1; pl.tm_per_chunk = pl.tiles_m;
-    const char *ce = getenv("STCN_WINO4_CHUNK_MB");                            // read per launch: tests run shapes under tiny chunks
-    const long chunk_bytes = (long)(ce ? atoi(ce) : 160) << 20;
+    const long chunk_bytes = (long)p.kn.wino4_chunk_mb << 20;                  // tests run shapes under tiny chunks
     const long vbytes = 36L * p.Cin * pl.Mt_pad * 4;
     if (pl.mb == 2 && chunk_bytes > 0 && vbytes > chunk_bytes * 3 / 2) {
         const int rounds = (pl.grid + cus - 1) / cus;

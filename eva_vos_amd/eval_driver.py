@@ -31,7 +31,7 @@ import numpy as np
 import torch
 
 from . import metrics, shard
-from .fq_driver import NO_OBJECT, ClipDataset, run_lanes
+from .fq_driver import NO_OBJECT, ClipDataset, lane_engine_options, run_lanes
 
 POLICIES = ("oracle_mask", "rand_mask", "qnet_mask", "upper_bound_mask")
 MASK_SECONDS, SKIP_SECONDS = 80, 3            # annotation cost model of interactions/mask.py:33-36
@@ -127,7 +127,7 @@ def run(root: str, imset: str, out_csv: str, prop_net, fuse_net, policy: str = "
 
     def work(i, sample):
         rows = []
-        proc = InferenceCore(prop_net, fuse_net, sample["rgb"], 1)
+        proc = InferenceCore(prop_net, fuse_net, sample["rgb"], 1, engine_options=lane_engine_options(lanes))
         res = run_policy(policy, proc, sample, rounds, metric, qnet, random.Random(seed * 100003 + i))
         for r, (mu, sec, q) in enumerate(zip(res["mu_metrics"], res["annotation_times"], res["round_metrics"])):
             row = np.full(width, np.nan, np.float32)

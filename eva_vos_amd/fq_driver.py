@@ -114,6 +114,14 @@ def prefetched(ds: "ClipDataset", indices, device: str = "cuda"):
             yield i, sample
 
 
+def lane_engine_options(lanes: int):
+    """Engine tunables for `lanes` videos in flight per GPU: the engines' own side streams (key-encoder look-ahead, FusionNet of
+    rounds >= 2) help ONE video in flight (+6..8 %); with several lanes the videos already fill each other's gaps and eight
+    streams only contend (second interactions -3 %).  Given to InferenceCore explicitly - the process environment is not touched
+    (an STCN_LOOKAHEAD set by the user still wins)."""
+    return {"lookahead": 0} if lanes > 1 and "STCN_LOOKAHEAD" not in os.environ else None
+
+
 def run_lanes(root: str, imset: str, mine, lanes: int, work, device: str = "cuda"):
     """Process the samples `mine` on `lanes` host threads, each with its own HIP stream, clip loader and prefetcher
     (samples are independent; two videos in flight fill each other's kernel tails, as bench.py's lanes do).
@@ -125,10 +133,6 @@ def run_lanes(root: str, imset: str, mine, lanes: int, work, device: str = "cuda
     on_gpu = torch.cuda.is_available() and str(device).startswith("cuda")
     dev_index = torch.cuda.current_device() if on_gpu else None
     bounds = [len(mine) * l // lanes for l in range(lanes + 1)]
-    if lanes > 1:
-        # the engines' own side streams (key-encoder look-ahead, FusionNet of rounds >= 2) help ONE video in flight (+6..8 %);
-        # with several lanes the videos already fill each other's gaps and eight streams only contend (second interactions -3 %)
-        os.environ.setdefault("STCN_LOOKAHEAD", "0")
 
     def lane(l):
         ds = ClipDataset(root, imset)
@@ -282,7 +286,7 @@ def run(root: str, imset: str, out: str, prop_net, fuse_net, rounds: int = 8, sa
                 saved_rgb.add(sample["video"])
             if first:
                 pending.append(save_rgb_frames(sample["rgb"][0], os.path.join(out, "RGBFrames", "224", sample["video"]), writers))
-        proc = InferenceCore(prop_net, fuse_net, sample["rgb"], 1)
+        proc = InferenceCore(prop_net, fuse_net, sample["rgb"], 1, engine_options=lane_engine_options(lanes))
         states, gens = oracle_rounds(proc, sample, rounds)
         sid = 1
         for r, ((worst, q), gen) in enumerate(zip(states, gens)):

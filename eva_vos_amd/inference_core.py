@@ -68,8 +68,11 @@ def _fingerprint(module) -> tuple:
     probe = []
     for i in sorted({(len(fl) - 1) * j // 7 for j in range(8)}) if fl else ():
         x = fl[i].detach().reshape(-1)[:4096].double()
-        probe.append((float(x.sum()), float(x.abs().sum())))
-    return ids + tuple(probe)
+        probe += [x.sum(), x.abs().sum()]
+    # ONE device-to-host transfer (and host sync) per module for all probes: the reference-style drivers build one core per sample
+    # from several lane threads, 16 blocking float() calls per module serialised them
+    vals = tuple(torch.stack([v.to(probe[0].device) for v in probe]).tolist()) if probe else ()
+    return ids + vals
 
 
 _SNAPSHOTS_PER_DEVICE = 4      # LRU: alternating a few (prop_net weights, fuse_net) pairs must not re-fold the model every time
@@ -92,9 +95,9 @@ def _model_for(prop_net, fuse_net, device_index: int) -> _Model:
     (one script evaluating several checkpoints) yields a fresh model.  A small LRU per (prop_net, device) keeps the last
     few snapshots, so alternating two fusion networks (or fuse_net / None) does not re-upload 218 MB per construction;
     older ones die with their last engine."""
+    key = (device_index, _fingerprint(prop_net), _fingerprint(fuse_net))      # outside the lock: it may sync the device
     with _MODEL_LOCK:                       # engines may be created from several host threads (one per video)
         per_net = _MODEL_CACHE.setdefault(prop_net, {})
-        key = (device_index, _fingerprint(prop_net), _fingerprint(fuse_net))
         hit = per_net.get(key)
         # the fuse_net is held weakly and compared by identity: a new module that happens to reuse a freed one's id /
         # storage addresses must not alias its packed weights
@@ -117,7 +120,10 @@ def _pad16(n: int):
 
 
 class InferenceCore:
-    def __init__(self, prop_net, fuse_net, images, num_objects, mem_profile=0, mem_freq=5, device="cuda"):
+    def __init__(self, prop_net, fuse_net, images, num_objects, mem_profile=0, mem_freq=5, device="cuda", engine_options=None):
+        """``engine_options`` (not in the reference; results never depend on it): dict with any of ``lookahead``, ``decode_batch``,
+        ``key_batch``, ``fuse_side`` - the engine's tunables given explicitly (include/stcn_hip.h: stcn_engine_opts) instead of
+        through the STCN_* environment variables, e.g. ``{"lookahead": 0}`` for drivers that keep several videos in flight."""
         if not torch.cuda.is_available():
             raise RuntimeError("eva_vos_amd.InferenceCore needs a HIP device (there is no CPU fallback); "
                                "the CPU oracle lives in oracle/ and is test infrastructure only")
@@ -138,14 +144,27 @@ class InferenceCore:
         self._model = _model_for(prop_net, fuse_net, self.device.index or 0)
         with torch.cuda.device(self.device):
             self._stream = torch.cuda.current_stream()
-            imgs = images.detach().to(self.device, torch.float32).contiguous()
-            self.prob = torch.empty((self.k + 1, self.t, 1, self.nh, self.nw), dtype=torch.float32, device=self.device)
-            self.masks = torch.empty((self.t, 1, self.nh, self.nw), dtype=torch.uint8, device=self.device)
+            def alloc():
+                return (images.detach().to(self.device, torch.float32).contiguous(),
+                        torch.empty((self.k + 1, self.t, 1, self.nh, self.nw), dtype=torch.float32, device=self.device),
+                        torch.empty((self.t, 1, self.nh, self.nw), dtype=torch.uint8, device=self.device))
+            try:
+                imgs, self.prob, self.masks = alloc()
+            except torch.cuda.OutOfMemoryError:
+                # the library parks the buffers of destroyed engines in its own pool (STCN_POOL_GB), outside PyTorch's caching
+                # allocator: hand them back to the driver and try once more before giving up
+                release_pooled_memory()
+                torch.cuda.empty_cache()
+                imgs, self.prob, self.masks = alloc()
             self.np_masks = np.zeros((self.t, self.h, self.w), dtype=np.uint8)
             h_ = C.c_void_p()
-            _lib.check(_lib.lib().stcn_engine_create(
+            eo = dict(engine_options or {})
+            opts = _lib.EngineOpts(*(int(eo.pop(n, -1)) for n, _ in _lib.EngineOpts._fields_))
+            if eo:
+                raise TypeError(f"unknown engine_options {sorted(eo)}")
+            _lib.check(_lib.lib().stcn_engine_create_ex(
                 self._model.handle, self.t, self.h, self.w, self.k, int(mem_freq), self._stream.cuda_stream,
-                imgs.data_ptr(), self.prob.data_ptr(), self.masks.data_ptr(), C.byref(h_)), "stcn_engine_create")
+                imgs.data_ptr(), self.prob.data_ptr(), self.masks.data_ptr(), C.byref(opts), C.byref(h_)), "stcn_engine_create")
         self._images_unpadded = imgs
         self._engine = h_
         self._finalizer = weakref.finalize(self, _lib.lib().stcn_engine_destroy, h_)

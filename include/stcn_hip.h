@@ -73,6 +73,19 @@ int stcn_engine_create(const stcn_model *m, int T, int H, int W, int k, int mem_
                        stcn_engine **out);
 int stcn_engine_destroy(stcn_engine *e);
 
+/* Engine tunables given explicitly instead of through the environment.  A NEGATIVE field means "not given": the engine then
+ * takes the environment variable (read once, while the engine is created) or its default.  Results never depend on them.
+ *   lookahead     STCN_LOOKAHEAD     (default 2)  0 = no side stream at all (drivers that keep several videos in flight per GPU)
+ *   decode_batch  STCN_DECODE_BATCH  (default 8)  frames per memory-read + decoder pass, clipped to mem_freq and 16 / k
+ *   key_batch     STCN_KEY_BATCH     (default 0 = max(4, decode group))  frames per key-encoder pass
+ *   fuse_side     STCN_FUSE_SIDE     (default 1)  FusionNet of rounds >= 2 on the side stream
+ * stcn_engine_create(...) = stcn_engine_create_ex(..., NULL, out).  A clone inherits its source's resolved values.
+ * (No reference counterpart: InferenceCore has no tuning surface; eva_vos_amd.InferenceCore(..., engine_options={...}).) */
+typedef struct { int32_t lookahead, decode_batch, key_batch, fuse_side; } stcn_engine_opts;
+int stcn_engine_create_ex(const stcn_model *m, int T, int H, int W, int k, int mem_freq,
+                          void *stream, const float *images_dev, float *prob_dev, uint8_t *masks_dev,
+                          const stcn_engine_opts *opts, stcn_engine **out);
+
 /* Back to the state right after stcn_engine_create (same clip): forgets interactions, certain memory and the
  * key-feature cache, re-initialises prob / masks.  Lets a driver reuse one engine's device memory for the
  * next sample of the same shape instead of re-allocating ~4.6 GB.  (No reference counterpart: the reference
@@ -91,7 +104,8 @@ int stcn_engine_clone(const stcn_engine *src, float *prob_dev, uint8_t *masks_de
  *                   the reference accepts (inference_core.py:220-233).
  *   Enqueues on the engine stream and returns without synchronising; prob_dev / masks_dev are
  *   complete once the stream has drained.
- *   Errors: bad arguments (STCN_E_INVALID) are detected before anything is touched.  A failure INSIDE the
+ *   Errors: bad arguments (STCN_E_INVALID) and a failing up-front reservation of bank memory (STCN_E_HIP: out of memory) are
+ *   detected before anything is touched - the engine stays usable, the call may be repeated.  A failure INSIDE the
  *   interaction (failed launch, out of memory while the bank grows) rolls the host bookkeeping back (set of
  *   interacted frames, certain-memory count) and puts the engine into a failed state: prob_dev / masks_dev hold
  *   a partially propagated round, further stcn_interact calls return STCN_E_STATE until stcn_engine_reset().
@@ -119,6 +133,12 @@ int stcn_get_flops(const stcn_engine *e, double *flops);
 int stcn_test_conv(void *stream, const float *x, const float *w, const float *bias, const float *res,
                    float *y, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
                    int pad, int flags, int splitk);
+
+/* Which kernel family the calling thread's last convolution (stcn_test_conv, or the last conv an interact() enqueued) ran as:
+ * "direct splitk=1", "direct_pointwise splitk=1", "direct_narrow ...", "direct_smallc ...", "direct_big ...", "... +tail ...",
+ * "wino2 ppw=1 splitk=2" (Winograd F(2x2,3x3)), "wino4 chunks=2 +tail" (F(4x4,3x3)), "fusion_wino", "fusion_direct", "n1".
+ * Tests assert the path per shape: a silent fall-back to another instance would still pass a numerical comparison. */
+const char *stcn_last_conv_path(void);
 
 /* encode_key of one frame (prop_net.py:172-177).  img: [1,3,nh,nw] NCHW padded.  Outputs (NHWC):
  * k16 [hw16,64], f16_thin [hw16,512], f16 [hw16,1024], f8 [hw8,512], f4 [hw4,256]; any may be NULL. */
@@ -168,8 +188,14 @@ int stcn_memread_plan(int N, int Q, int32_t *plan7);
 int stcn_pool_release(void);
 
 /* Test hook (fault injection): the n-th kernel-launch status check made by the CALLING THREAD from now on reports a
- * failure (n = 0 disarms).  Used to show that a failing stcn_interact leaves the engine in a defined state. */
+ * failure (n = 0 disarms).  Used to show that a failing stcn_interact leaves the engine in a defined state.
+ * n = -1: the next stcn_interact of the calling thread fails in its up-front memory reservation - before anything is touched:
+ * that call returns STCN_E_HIP and the engine stays USABLE (no failed state). */
 int stcn_test_fail_at(int n);
+
+/* Test hook (stream ordering): every FusionNet group handed to the engine's side stream starts `us` microseconds late (0: off;
+ * process-wide).  Orderings between the two streams that rest on events alone become observable: a missing wait is a wrong result. */
+int stcn_test_side_delay_us(int us);
 
 /* Time `iters` launches of the dominant kernel (implicit-GEMM conv) on `stream` with HIP events;
  * returns average milliseconds per launch.  Used by bench.py for the roofline object. */

@@ -259,7 +259,10 @@ FULL_CASES = {
     "seq480": dict(H=480, W=854, k=1, T=6, mem_freq=2, script=[(0, 0), (4, 4)], prob_stride=4),
     # BASELINE config 3 shape from the reference: 5 objects through the scribble / (k+1)-channel path, every frame enters the
     # bank (mem_freq = 1), 12 frames 480x854; uint8 masks + every 8th prob sample as fp16.  Self-noise on 1 / 4 / 8 threads.
-    "seq480k5": dict(H=480, W=854, k=5, T=12, mem_freq=1, script=[(0, 0)], prob_stride=8, threads=(1, 4, 8), decisive_eps=1e-2),
+    # Round 4: under the MULTI-OBJECT weight recipe (seed 2: eva_vos_amd/synth.py RECIPES, oracle/calibrate_multi.py,
+    # oracle/fit_multi_pred.py) - the decoder separates the objects, > 99 % of the pixels carry a decisive label in the
+    # reference's own output and its thread counts agree to a handful of pixels: parity is stated on ALL pixels.
+    "seq480k5": dict(H=480, W=854, k=5, T=12, mem_freq=1, script=[(0, 0)], prob_stride=8, threads=(1, 4, 8), decisive_eps=1e-2, seed=2),
 }
 STAGE_CASES = {
     "stA": dict(H=128, W=160, k=1),

@@ -46,6 +46,24 @@ def nets(weights):
     return p.eval(), f.eval()
 
 
+@pytest.fixture(scope="session")
+def weights_multi():
+    """The MULTI-OBJECT recipe (seed 2: Philox draws + the fitted last layers, eva_vos_amd/synth.py RECIPES): the decoder separates
+    several objects, so multi-object mask parity can be stated on (almost) all pixels."""
+    from eva_vos_amd import synth
+    from eva_vos_amd.params import FusionNet, PropagationNetwork
+    return synth.recipe_state_dict(PropagationNetwork(), 2), synth.recipe_state_dict(FusionNet(), 2)
+
+
+@pytest.fixture(scope="session")
+def nets_multi(weights_multi):
+    from eva_vos_amd.params import FusionNet, PropagationNetwork
+    p, f = PropagationNetwork(), FusionNet()
+    p.load_state_dict(weights_multi[0], strict=True)
+    f.load_state_dict(weights_multi[1], strict=True)
+    return p.eval(), f.eval()
+
+
 def load_golden(tag):
     return dict(np.load(os.path.join(GOLD, f"{tag}.npz")))
 

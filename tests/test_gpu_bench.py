@@ -69,6 +69,37 @@ def test_davis_val_workload_is_sharded_by_lpt_over_the_ranks():
     assert max(dv["rank_busy_fraction"]) == 1.0 and dv["imbalance_max_over_mean_frames"] < 1.2
 
 
+TINY = ["--warmup", "0", "--frames", "5", "--height", "128", "--width", "160", "--streams", "1", "--no-profile", "--no-r2",
+        "--cpu-frames", "0", "--no-config3", "--no-memread-roofline"]
+
+
+def test_eight_rank_preflight_on_one_device():
+    """The driver's first real `bench.py --gpus 8` must not fail on rendezvous, row width or an empty rank: both workloads with
+    EIGHT ranks over gloo on this box's one device at a tiny size (eval_annotation_method.py:34-35,113-119 shards the same way
+    by hand).  Uniform: 8 gathered J&F rows, ranks 0..7, 8 x the frames.  davis-val: the 30 samples once each, no rank empty,
+    and the LPT assignment of the TRUE lengths (34..104 frames) balanced to 1 % over 8 ranks."""
+    env = {"STCN_BENCH_DEVICE": "0", "STCN_BENCH_BACKEND": "gloo"}
+    uni = run_bench(["--gpus", "8", "--steps", "1", "--no-davis-val"] + TINY, env)
+    assert uni["n_gpus"] == 8 and uni["scaling"] == "weak"
+    rows = uni["jf_rows_rank_J_F_JF"]
+    assert [int(r[0]) for r in rows] == list(range(8)) and all(len(r) == 4 for r in rows)
+    assert all(r[1:] == rows[0][1:] for r in rows), "same clip and weights on every rank"
+    frames = uni["value"] * uni["ms_per_step"] * 1e-3 * uni["steps"]
+    assert abs(frames - 8 * 1 * 4) < 1e-3
+    dvl = run_bench(["--gpus", "8", "--steps", "30", "--workload", "davis-val", "--davis-max-frames", "4"] + TINY, env)
+    dv = dvl["davis_val"]
+    assert dvl["n_gpus"] == 8 and dvl["scaling"] == "strong" and dv["samples"] == 30
+    assert dv["frames_total"] == 30 * 3 and sum(dv["rank_samples"]) == 30 and min(dv["rank_samples"]) >= 1
+    assert len(dv["rank_seconds"]) == 8 and max(dv["rank_busy_fraction"]) == 1.0
+    from eva_vos_amd import shard
+    sys.path.insert(0, ROOT)
+    import bench
+    lens = [t - 1 for t in bench.DAVIS_VAL_LENGTHS]
+    loads = [sum(lens[i] for i in part) for part in shard.lpt_assign(lens, 8)]
+    assert sorted(i for part in shard.lpt_assign(lens, 8) for i in part) == list(range(30))
+    assert max(loads) / (sum(loads) / 8) <= 1.01, loads
+
+
 def test_real_data_hook_is_taken_when_checkpoints_and_clips_exist(tmp_path):
     """eval_annotation_method.py:51-64 loads ./model_weights/mivos/{stcn,fusion}.pth and ./data/DAVIS_17: when both exist
     bench.py measures on real clips and says so.  Here: the recipe weights saved as checkpoints + a synthetic tree in the

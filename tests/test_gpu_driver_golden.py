@@ -1,0 +1,63 @@
+"""GPU: the callers either side of the path ON THE DEVICE against the fixtures captured from the reference
+(oracle/gen_golden_driver.py -> tests/golden/driver.npz): the clip loader's pinned-memory / side-stream upload
+(eva_vos_amd.fq_driver.prefetched) vs datasets/annotation_dataset.py:80-132, and the FQ-dataset writer fed with device
+tensors (resizes on the GPU) vs util/fq_dataset.py:26-91.  CPU twins: tests/test_driver_golden.py."""
+import os
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from conftest import load_golden
+from eva_vos_amd import fq_driver
+from test_driver_golden import TREE
+
+pytestmark = pytest.mark.gpu
+
+
+def test_prefetched_device_clips_equal_the_reference_dataset(tmp_path):
+    """What the engines actually consume: sample['rgb'] as a DEVICE tensor, decoded on a host thread into pinned memory and
+    copied on a side stream while the previous sample is in use - value for value the reference loader's tensor."""
+    g = load_golden("driver")
+    imset = fq_driver.make_synthetic_tree(str(tmp_path), TREE)
+    ds = fq_driver.ClipDataset(str(tmp_path), imset)
+    seen = []
+    for i, smp in fq_driver.prefetched(ds, range(len(ds)), "cuda"):
+        rgb, gt = smp["rgb"], smp["gt"]
+        assert rgb.is_cuda and rgb.dtype == torch.float32 and rgb.shape[0] == 1
+        # keep the device busy between samples, as a propagation would: the next upload overlaps this work
+        _ = (torch.randn(512, 512, device="cuda") @ torch.randn(512, 512, device="cuda")).sum().item()
+        assert list(rgb[0].shape) == g[f"s{i}.rgb_shape"].tolist() and list(gt.shape) == g[f"s{i}.gt_shape"].tolist()
+        assert smp["num_frames"] == int(g[f"s{i}.num_frames"]) and smp["name"] == g["names"].tolist()[i]
+        assert np.abs(rgb[0].reshape(-1)[::101].cpu().numpy() - g[f"s{i}.rgb_sample"]).max() < 5e-7
+        assert abs(float(rgb[0].double().abs().sum()) - g[f"s{i}.rgb_sum"][1]) < 1e-3
+        want = np.unpackbits(g[f"s{i}.gt"])[: gt.numel()].reshape(gt.shape).astype(bool)
+        assert np.array_equal(gt.cpu().numpy() > 0.5, want)
+        seen.append(i)
+    assert seen == list(range(len(ds)))
+
+
+def test_fq_writer_from_device_tensors_equals_the_reference_writer(tmp_path):
+    """save_state_masks / save_rgb_frames with DEVICE inputs (the resizes run on the GPU; PNG encoding on host threads, as the
+    driver uses them): mask PNGs byte-exact, RGB within 1 LSB of util/fq_dataset.py's output."""
+    from concurrent.futures import ThreadPoolExecutor
+    g = load_golden("driver")
+    n, T, H, W = [int(v) for v in g["writer.gen_shape"]]
+    gens = np.unpackbits(g["writer.gen"])[: n * T * H * W].reshape(n, T, H, W)
+    with ThreadPoolExecutor(2) as pool:
+        futs = []
+        for sid in (1, 2):
+            futs.append(fq_driver.save_state_masks(torch.from_numpy(gens[sid - 1]).cuda(), str(tmp_path / f"state{sid}"), pool))
+        imset = fq_driver.make_synthetic_tree(str(tmp_path / "db"), TREE)
+        ds = fq_driver.ClipDataset(str(tmp_path / "db"), imset)
+        _, smp = next(iter(fq_driver.prefetched(ds, [0], "cuda")))
+        futs.append(fq_driver.save_rgb_frames(smp["rgb"][0], str(tmp_path / "rgb"), pool))
+        for f in futs:
+            f.result()
+    for sid in (1, 2):
+        got = np.stack([np.array(Image.open(os.path.join(str(tmp_path / f"state{sid}"), f"{t:05d}.png"))) for t in range(T)])
+        assert got.dtype == np.uint8 and np.array_equal(got, g[f"writer.masks{sid}"])
+    got = np.stack([np.array(Image.open(os.path.join(str(tmp_path / "rgb"), f"{t:05d}.png"))) for t in range(T)])
+    assert got.shape == g["writer.rgb224"].shape
+    assert np.abs(got.astype(int) - g["writer.rgb224"].astype(int)).max() <= 1

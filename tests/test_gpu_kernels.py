@@ -65,12 +65,36 @@ CONVS = [
 ]
 
 
+# the kernel family every CONVS case must run as (prefix of stcn_last_conv_path() in the default variant): a shape that silently
+# falls back to another instance would still pass the numerical comparison below
+PATHS = [
+    "direct_pointwise", "wino2", "direct splitk=1", "direct splitk=4", "direct splitk", "direct_smallc", "direct_smallc",
+    "fusion_wino", "fusion_wino", "fusion_wino", "fusion_wino", "fusion_wino", "direct_pointwise", "wino2", "n1", "n1", "n1",
+    "direct +tail", "direct_narrow +tail", "direct_smallc +tail",
+    "wino2", "wino2", "wino2", "wino2", "wino2",
+    "wino2", "wino2", "wino2",
+    "wino4", "wino4", "wino4", "wino4", "wino4", "wino4",
+    "wino4 chunks=1 +tail", "wino4",
+    "wino4",
+    "direct_pointwise", "direct_pointwise splitk=3", "direct splitk",
+]
+
+
+def last_path():
+    from eva_vos_amd import _lib
+    return _lib.lib().stcn_last_conv_path().decode()
+
+
 def _is_wino(Cin, Cout, K, s, splitk, tiles=0):
     return K == 3 and s == 1 and (Cin >= 128 or (Cin == 64 and tiles >= 16384)) and Cin % 32 == 0 and Cout % 64 == 0 and splitk == 0
 
 
-@pytest.mark.parametrize("B,H,W,Cin,Cout,K,s,flags,splitk", CONVS)
-def test_conv_matches_fp64_reference(B, H, W, Cin, Cout, K, s, flags, splitk, monkeypatch):
+def test_the_path_table_covers_every_case():
+    assert len(PATHS) == len(CONVS)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,K,s,flags,splitk,path", [c + (p,) for c, p in zip(CONVS, PATHS)])
+def test_conv_matches_fp64_reference(B, H, W, Cin, Cout, K, s, flags, splitk, path, monkeypatch):
     g = torch.Generator().manual_seed(Cin * 131 + Cout * 7 + K)
     x = torch.randn(B, Cin, H, W, generator=g)
     w = torch.randn(Cout, Cin, K, K, generator=g) * (2.0 / (Cin * K * K)) ** 0.5
@@ -106,6 +130,12 @@ def test_conv_matches_fp64_reference(B, H, W, Cin, Cout, K, s, flags, splitk, mo
         got = y.permute(0, 3, 1, 2).cpu().double()
         err = (got - ref).abs().max().item() / ref.abs().max().item()
         assert err < 2e-5, (err, ppw)          # fp32 accumulation vs fp64
+        # ... and it ran as the kernel this case is in the list for
+        ran = last_path()
+        want = {"direct": "fusion_direct", "1": "wino2 ppw=1", "2": "wino2 ppw=2", "chunk": "wino4"}.get(ppw, path)
+        assert ran.startswith(want), (ran, want)
+        if ppw == "chunk" and (B, H, W, Cin, Cout) == (2, 120, 216, 128, 256):
+            assert "chunks=2" in ran, ran
 
 
 def _random_conv_cases():
@@ -131,12 +161,13 @@ def _random_conv_cases():
             Cin, Cout, K, s = int(rng.choice([64, 96, 256])), int(rng.choice([32, 64, 160, 256])), 1, 1
         else:
             Cin, Cout, K, s = int(rng.choice([64, 128])), int(rng.choice([64, 128])), 3, 2
-        cases.append((B, H, W, Cin, Cout, K, s, flags, res))
+        cases.append((B, H, W, Cin, Cout, K, s, flags, res, {"f2": "wino2", "f4": "wino4", "fusion": "fusion_wino", "direct1x1": "direct_pointwise",
+                                                              "direct3x3s2": "direct s"}[kind]))
     return cases
 
 
-@pytest.mark.parametrize("B,H,W,Cin,Cout,K,s,flags,use_res", _random_conv_cases())
-def test_conv_random_shapes_match_fp64_reference(B, H, W, Cin, Cout, K, s, flags, use_res):
+@pytest.mark.parametrize("B,H,W,Cin,Cout,K,s,flags,use_res,path", _random_conv_cases())
+def test_conv_random_shapes_match_fp64_reference(B, H, W, Cin, Cout, K, s, flags, use_res, path):
     g = torch.Generator().manual_seed(B * 1000003 + H * 10007 + W * 101 + Cin + Cout)
     x = torch.randn(B, Cin, H, W, generator=g)
     w = torch.randn(Cout, Cin, K, K, generator=g) * (2.0 / (Cin * K * K)) ** 0.5
@@ -155,6 +186,7 @@ def test_conv_random_shapes_match_fp64_reference(B, H, W, Cin, Cout, K, s, flags
     assert torch.isfinite(got).all()
     err = (got - ref).abs().max().item() / ref.abs().max().item()
     assert err < 2e-5, err
+    assert last_path().startswith(path), (last_path(), path)       # the kernel family the case was drawn for
 
 
 def _memread(mk, mv, qk):

@@ -529,6 +529,57 @@ def test_a_failing_interaction_leaves_a_defined_state(nets):
     assert np.array_equal(core.interact(msk[:, 2], 2), want1)
 
 
+def test_an_up_front_out_of_memory_does_not_cost_the_session(nets):
+    """stcn_interact reserves the bank memory of the whole interaction BEFORE its first mutation; a failure there (injected:
+    stcn_test_fail_at(-1)) has touched nothing, so the call raises and the engine stays USABLE - earlier rounds are not lost,
+    the same interaction can simply be repeated (advisor, round 3)."""
+    from eva_vos_amd import _lib
+    T, H, W = 9, 112, 144
+    img, msk = synth.synthetic_clip(T, H, W, seed=13), synth.synthetic_mask(T, H, W, 1, seed=14)
+    ref = make_core(nets)(img, 1, 3)
+    want1 = ref.interact(msk[:, 2], 2).copy()
+    want2 = ref.interact(msk[:, 6], 6).copy()
+    core = make_core(nets)(img, 1, 3)
+    assert np.array_equal(core.interact(msk[:, 2], 2), want1)
+    prob1 = core.prob.clone()
+    _lib.check(_lib.lib().stcn_test_fail_at(-1))
+    with pytest.raises(RuntimeError, match="bank_reserve"):
+        core.interact(msk[:, 6], 6)
+    assert core.interacted == {2} and torch.equal(core.prob, prob1), "nothing may have been touched"
+    assert np.array_equal(core.interact(msk[:, 6], 6), want2) and torch.equal(core.prob, ref.prob)
+
+
+@pytest.mark.parametrize("mf,batch,second", [(2, "1", 2), (2, None, 2), (3, "1", 1), (1, "1", 3), (5, None, 1)])
+def test_a_slow_side_stream_cannot_corrupt_the_aggregate_buffers(nets, monkeypatch, mf, batch, second):
+    """FusionNet of a decoded group runs on the engine's side stream out of one of two aggregate buffers while the main stream
+    goes on decoding.  Round 2 BELOW an earlier interaction: the forward sweep is fused (offloaded), the backward sweep that
+    follows is not - its first decode writes aggregate buffer 0 and has to wait for the side stream if the last offloaded group
+    still reads it (advisor, round 3: that wait was missing).  With every offloaded group delayed by 30 ms the race is certain
+    without the wait; the result must equal the same session with FusionNet in line (STCN_FUSE_SIDE=0), bit for bit."""
+    from eva_vos_amd import _lib
+    T, H, W = 13, 112, 144
+    img, msk = synth.synthetic_clip(T, H, W, seed=51), synth.synthetic_mask(T, H, W, 1, seed=52)
+    if batch:
+        monkeypatch.setenv("STCN_DECODE_BATCH", batch)
+    script = [(7, 7), (second, second), (10, 10), (4, 4)]          # below, above, between earlier interactions
+    outs = []
+    for side in ("0", "1"):
+        monkeypatch.setenv("STCN_FUSE_SIDE", side)
+        core = make_core(nets)(img, 1, mf)
+        _lib.check(_lib.lib().stcn_test_side_delay_us(30000 if side == "1" else 0))
+        try:
+            res = [core.interact(msk[:, f], i).copy() for f, i in script]
+            fused = core.stats()["fused"]
+            torch.cuda.synchronize()
+        finally:
+            _lib.check(_lib.lib().stcn_test_side_delay_us(0))
+        outs.append((res, core.prob.clone()))
+        assert fused > 0
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert np.array_equal(a, b)
+    assert torch.equal(outs[0][1], outs[1][1])
+
+
 def test_weight_snapshots_are_kept_per_fusion_net_and_data_writes_are_seen(weights):
     """Advisor items of round 2: (i) alternating two fusion networks with one propagation network must not rebuild the
     model every time (small LRU of snapshots); (ii) a whole-model update through ``.data`` (no version bump) is caught by
@@ -546,12 +597,14 @@ def test_weight_snapshots_are_kept_per_fusion_net_and_data_writes_are_seen(weigh
     assert IC._model_for(p, f1, 0) is not m1, "a .data update of every tensor must yield a fresh snapshot"
 
 
-def test_480p_multi_object_decode_groups_match_the_oracle(nets, weights):
+def test_480p_multi_object_decode_groups_match_the_oracle(nets_multi, weights_multi):
     """The k > 1 decode-group path (objects x frames in one batch, per-frame tensors broadcast by a modulo batch index) at the
-    BASELINE resolution against the CPU oracle: 480x854, 3 objects, mem_freq = 3 (groups of 3 frames), two rounds with fusion.
-    Statements as for the `seq480k5` fixture: per-object mask IoU on the pixels whose label is well-conditioned in the ORACLE's
-    own probabilities (top-1 minus top-2 >= 1e-2; elsewhere the argmax hangs on fp32 rounding, section 2 of DESIGN.md), on the
-    clip and on every frame; probabilities everywhere, tail against 3 x the reference's own tail at 480p with several objects."""
+    BASELINE resolution against the CPU oracle: 480x854, 3 objects, mem_freq = 3 (groups of 3 frames), two rounds with fusion,
+    under the MULTI-OBJECT weight recipe (seed 2) on a clip the recipe's fitted layers have not seen as k = 3.  Per-object mask
+    IoU over ALL pixels, on the clip and on every frame, against max(1e-3, 3 x the reference's own envelope on the 480p
+    five-object fixture); the pixels whose label is well-conditioned in the oracle's own probabilities (top-1 minus top-2
+    >= 1e-2) must be at least 80 % of the frame - otherwise the comparison would speak for a minority (round 3: 22 %)."""
+    nets, weights = nets_multi, weights_multi
     T, H, W, k = 8, 480, 854, 3
     img, msk = synth.synthetic_clip(T, H, W, seed=41), synth.synthetic_mask(T, H, W, k, seed=42)
     core = make_core(nets)(img, k, 3)
@@ -564,17 +617,13 @@ def test_480p_multi_object_decode_groups_match_the_oracle(nets, weights):
         po = orc.prob[:, :, 0, lh:orc.prob.shape[3] - uh if uh else None, lw:orc.prob.shape[4] - uw if uw else None]
         top = torch.topk(po, 2, dim=0).values
         dec = ((top[0] - top[1]) >= 1e-2).numpy()
-        assert dec.mean() > 0.1, "hardly any decisive pixel: the comparison would be vacuous"
-        for o in range(1, k + 1):
-            ma, mb = (a == o) & dec, (b == o) & dec
-            assert iou(ma, mb) >= 1 - 1e-3, (idx, o, iou(ma, mb))
-            miss, fr = frame_miss(ma, mb)
-            px = (ma[fr] | mb[fr]).sum() if fr >= 0 else 1
-            assert miss <= frame_bound(0.0, px), (idx, o, fr, miss)
+        assert dec.mean() > 0.8, f"only {100 * dec.mean():.1f} % decisive pixels: the comparison would speak for a minority of the frame"
         d = (core.prob.cpu() - orc.prob).abs().numpy()
         q999 = float(np.quantile(d.reshape(-1)[::5], 0.999))
-        print(f"480p k=3 groups, interact({idx}): {100 * dec.mean():.1f} % decisive pixels, {int((a != b).sum())} mask pixels differ in all, "
-              f"{int(((a != b) & dec).sum())} on decisive pixels; |dprob| p99.9 {q999:.1e} max {d.max():.1e}")
+        print(f"480p k=3 groups, interact({idx}): {100 * dec.mean():.1f} % decisive pixels, {int((a != b).sum())} of {a.size} mask pixels differ "
+              f"({int(((a != b) & dec).sum())} on decisive pixels); |dprob| p99.9 {q999:.1e} max {d.max():.1e}")
+        masks_close(a, b, k, f"480p k=3 interact({idx})", yard=noise)
+        assert all((b[t] == o).sum() >= 256 for o in range(1, k + 1) for t in range(T)), "an object vanished in the oracle"
         assert q999 <= 3 * float(noise[2]) + 5e-4, (idx, q999)
     s_ = core.stats()
     assert s_["fused"] > 0 and s_["frames"] == T - 2

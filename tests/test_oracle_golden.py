@@ -135,33 +135,29 @@ def check_sequence_against_golden(outs, tag, g, prob_atol, min_iou=1 - 1e-3, tie
         ref_masks = g[f"{tag}.r{r}.masks"]
         if k == 1:
             ref_masks = np.unpackbits(ref_masks)[: T * H * W].reshape(T, H, W)
-        # Fixtures with a `decisive` bitmask (seq480k5): the pixels whose label is well-conditioned in the REFERENCE's own
-        # probabilities (top-1 minus top-2 >= 1e-2 = what one swapped top-50 member at a near-tie moves its neighbourhood by).
-        # With 5 objects the random-recipe decoder leaves most of the frame at p ~ 1/(k+1) in every row; there the argmax hangs
-        # on fp32 rounding (the reference's own thread counts disagree on 4297 pixels, two correct fp32 implementations with
-        # different rounding - BN folded or not - on ~2e4, all of them inside that margin), so mask parity is stated on the
-        # decisive pixels, at the north_star bound, and the probabilities are compared everywhere below.
-        dec = None
+        # Fixtures with a `decisive` bitmask (seq480k5, the MULTI-OBJECT weight recipe: synth.RECIPES[2]): the pixels whose label
+        # is well-conditioned in the REFERENCE's own probabilities (top-1 minus top-2 >= 1e-2 = what one swapped top-50 member at
+        # a near-tie moves its neighbourhood by).  Round 3 stated mask parity on those pixels only - 27 % of the frame under the
+        # plain random recipe, whose decoder answers every object with the same logit.  Under the multi-object recipe they are
+        # > 99 % of the frame: the bitmask is kept as a GUARD that the fixture is not vacuous, and parity is asserted on ALL pixels.
         if f"{tag}.r{r}.decisive" in g:
             dec = np.unpackbits(g[f"{tag}.r{r}.decisive"])[: T * H * W].reshape(T, H, W).astype(bool)
-            print(f"{who} vs golden {tag} r{r}: {100 * dec.mean():.1f} % of the pixels decisive (eps {float(g[f'{tag}.decisive_eps']):.0e}); "
-                  f"mask pixels differing: {int((masks != ref_masks).sum())} in all, {int(((masks != ref_masks) & dec).sum())} on decisive pixels")
+            print(f"{who} vs golden {tag} r{r}: {100 * dec.mean():.2f} % of the pixels decisive in the reference (eps {float(g[f'{tag}.decisive_eps']):.0e}); "
+                  f"mask pixels differing: {int((masks != ref_masks).sum())} of {masks.size} in all, {int(((masks != ref_masks) & dec).sum())} on decisive pixels; "
+                  f"smallest object on a propagated frame: {min(int((ref_masks[1:] == o).reshape(T - 1, -1).sum(1).min()) for o in range(1, k + 1))} px")
+            assert dec.mean() >= 0.9, "the multi-object recipe no longer separates the objects: the fixture would be vacuous"
+            assert all((ref_masks[1:] == o).reshape(T - 1, -1).sum(1).min() >= 256 for o in range(1, k + 1)), "an object vanished in the reference"
         # (1b) per FRAME and object (a volume IoU hides one bad frame among many): 1e-3, or 3 x the reference's own worst
         # per-frame difference between its thread counts on this round (selfnoise column 4), or two pixels
         for o in range(1, k + 1):
             ma, mb = masks == o, ref_masks == o
-            if dec is not None:
-                ma, mb = ma & dec, mb & dec
             miss, fr = frame_miss(ma, mb)
             px = (ma[fr] | mb[fr]).sum() if fr >= 0 else 1
-            fb = frame_bound(0.0 if dec is not None else noise[r][4], px)
+            fb = frame_bound(noise[r][4], px)
             print(f"{who} vs golden {tag} r{r} object {o}: worst frame {fr} 1-IoU {miss:.2e} (bound {fb:.2e})")
             assert miss <= fb, (tag, r, o, fr, miss, fb)
         if k == 1:
             assert iou(masks > 0, ref_masks > 0) >= min_iou, (tag, r)
-        elif dec is not None:
-            for o in range(1, k + 1):
-                assert iou((masks == o) & dec, (ref_masks == o) & dec) >= min_iou, (tag, r, o)
         else:
             # selfnoise = worst pair of the reference against ITSELF (1 / 2 / 4 / 8 threads) on this sequence.  With k > 1 the
             # aggregation is ill-conditioned where two objects saturate (p = 1 - 1e-7 after the clamp of aggregate.py:27: the
@@ -170,7 +166,9 @@ def check_sequence_against_golden(outs, tag, g, prob_atol, min_iou=1 - 1e-3, tie
             # object of seqC against an envelope of 1.16e-3); still below the 5e-3 of round 1, and k = 1 stays at 1e-3
             bound = max(1e-3, 3 * float(noise[r][0]))
             for o in range(1, k + 1):
-                assert 1 - iou(masks == o, ref_masks == o) <= bound, (tag, r, o, 1 - iou(masks == o, ref_masks == o), bound)
+                miss = 1 - iou(masks == o, ref_masks == o)
+                print(f"{who} vs golden {tag} r{r} object {o}: clip 1-IoU {miss:.2e} over ALL pixels (bound {bound:.2e})")
+                assert miss <= bound, (tag, r, o, miss, bound)
         ph = prob[:, :, 0, ::st, ::st].numpy()
         d = np.abs(ph - g[f"{tag}.r{r}.prob_h"].astype(np.float32))
         if ties is not None:
