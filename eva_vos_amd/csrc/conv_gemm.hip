@@ -65,12 +65,16 @@ __device__ __forceinline__ void tile_to_mn(int tile, int tiles_n, int ntile, int
 // WM x WN waves per workgroup, each owning RM x RN accumulator blocks of 32x32: workgroup tile (32 WM RM) x (32 WN RN).
 // PW: pointwise instance (1x1, stride 1, one dense source): no tap walk, no validity masks, no row decode - the set-up and
 // per-K-tile scalar code of the general instance is as long as the MFMA work of an 8-K-tile ResNet 1x1 conv.
-// STCN_PW_WAVES (build-time experiment): waves per SIMD the pointwise / plain 64x64 instances are compiled for (registers <= 512 / n)
+// STCN_PW_WAVES: waves per SIMD the one-accumulator-block instances (64x64 and 128x32 tiles, pointwise or not) are compiled for -
+// at most 512 / n registers.  hipcc's own choice was 136 registers = 3 workgroups per CU; 4 (118 registers, no spills) puts a
+// fourth workgroup on the CU behind which the short-K layers (8 K tiles between a prologue and a residual epilogue) hide their
+// latencies: conv_gemm kernels of the solo R1 leg 118.4 -> 112.9 ms, whole leg 378.3 -> 374.1 ms (tools/gpu_ab_trace.sh, 3 alternating
+// repetitions, gpurun_out/r4a/ab_pw_waves.txt).  -DSTCN_PW_WAVES=1 restores the compiler's choice.
 #ifndef STCN_PW_WAVES
-#define STCN_PW_WAVES 1
+#define STCN_PW_WAVES 4
 #endif
 template <int WM, int WN, int RM, int RN, bool SMALLC, bool RELU, bool PW = false>
-__global__ __launch_bounds__(256, (RM == 1 && RN == 1 && !SMALLC) ? STCN_PW_WAVES : 1) void conv_gemm_kernel(const ConvP p, const int tiles_n,
+__global__ __launch_bounds__(256, (RM == 1 && RN == 1) ? STCN_PW_WAVES : 1) void conv_gemm_kernel(const ConvP p, const int tiles_n,
                                                         const int ntile, const int kt_per_split, const TileDiv td) {
     constexpr int PA = WM * RM, PB = WN * RN;          // 32-row pieces of the A / B tiles (= staging chunks per thread)
     constexpr int BM = 32 * PA, BN = 32 * PB;

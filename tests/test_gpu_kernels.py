@@ -161,8 +161,10 @@ def _random_conv_cases():
             Cin, Cout, K, s = int(rng.choice([64, 96, 256])), int(rng.choice([32, 64, 160, 256])), 1, 1
         else:
             Cin, Cout, K, s = int(rng.choice([64, 128])), int(rng.choice([64, 128])), 3, 2
-        cases.append((B, H, W, Cin, Cout, K, s, flags, res, {"f2": "wino2", "f4": "wino4", "fusion": "fusion_wino", "direct1x1": "direct_pointwise",
-                                                              "direct3x3s2": "direct s"}[kind]))
+        path = {"f2": "wino2", "f4": "wino4", "fusion": "fusion_wino", "direct1x1": "direct_pointwise", "direct3x3s2": "direct s"}[kind]
+        if kind == "direct1x1" and Cout <= 32:
+            path = "direct_narrow s"                        # Cout <= 32: the 128x32-tile instance (no pointwise form of it)
+        cases.append((B, H, W, Cin, Cout, K, s, flags, res, path))
     return cases
 
 

@@ -629,6 +629,26 @@ def test_480p_multi_object_decode_groups_match_the_oracle(nets_multi, weights_mu
     assert s_["fused"] > 0 and s_["frames"] == T - 2
 
 
+def test_eight_round_annotation_session_at_480p_matches_the_oracle(nets, weights):
+    """The reference's annotation loops run 8 (interactions/mask.py:113-146) to 60 (eval_annotation_method.py:30) interactions per
+    sample; rounds 1-3 were compared at small sizes only.  Here a whole 8-round session of the oracle mask policy (annotate frame 0,
+    then the frame with the worst J against the ground truth; annotated frames count with their ground truth) at the BASELINE
+    resolution, T = 34 (the shortest DAVIS-val clip), HIP engine against the CPU oracle after EVERY round: growing certain memory
+    (8 slots), duplicate-free but ever shorter spans, fusion on both sides of earlier interactions.  Per round: clip IoU >= 1 - 1e-3
+    (north_star) and the worst frame against max(1e-3, 3 x the reference's own worst per-frame self-difference at 480p)."""
+    import bench
+    noise = load_golden("selfnoise")["seq480"].max(0)
+    res = bench.session_parity(nets[0], nets[1], weights[0], weights[1], 480, 854, 34, 8, 5)
+    print(res["session"], res["frames_annotated"])
+    assert len(set(res["frames_annotated"])) == 8 and res["last_round_stats"]["bank_fwd"] >= 8
+    for r in res["rounds"]:
+        print(f"round {r['round']} (frame {r['frame']}): clip IoU {r['mask_iou']:.6f}, worst frame {r['min_frame_iou']:.6f} @ {r['min_frame_iou_frame']}, "
+              f"{r['mask_pixels_differing']} px differ, next frame oracle / HIP {r['next_frame_oracle']} / {r['next_frame_hip']}")
+        assert r["mask_iou"] >= 1 - 1e-3, r
+        assert 1 - r["min_frame_iou"] <= max(1e-3, 3 * float(noise[4])), r
+        assert abs(r["mean_j_oracle"] - r["mean_j_hip"]) < 1e-4, r
+
+
 _POOL_SCRIPT = r"""
 import sys, torch
 sys.path.insert(0, %r)

@@ -22,6 +22,12 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_r2 -o r -- pyth
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_r1 -o r -- python3 $R/tools/r2_profile.py --no-class-profile --rounds 1 > $O/trace_r1.log 2>&1
 python3 $R/tools/r2_profile.py > $O/r2_profile.txt 2>&1
 cd $R && bash tools/pmc_f4.sh "256->256 @4" 5 > $O/pmc_wino4.txt 2>&1; cd /tmp
+# round 4: matrix-pipe occupancy per kernel of the solo R1 leg (SQ counters, own pass), the memory read at k = 1 (what config 2 runs),
+# and the F(4x4)-decoder A/B of pixels differing from the CPU oracle
+STCN_LOOKAHEAD=0 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmcSQ -o p -- python3 $R/bench.py --steps 1 --warmup 1 --streams 1 --no-profile $Q > $O/pmcSQ.log 2>&1
+python3 $R/tools/mfma_busy.py $(find $O/pmcSQ -name "p_counter_collection.csv" | head -1) --md > $O/mfma_busy.md 2>&1
+python3 $R/tools/memread_bench.py --k 1 > $O/memread_k1.txt 2>&1
+python3 $R/tools/wino4_ab_parity.py > $O/wino4_ab_parity.txt 2>&1
 find $O -name "r_kernel_trace.csv" -delete; find $O -name "p_kernel_trace.csv" -delete       # large, not needed for the summaries
 git -C $R rev-parse --short HEAD > $O/commit.txt 2>/dev/null || echo "${GRAFT_COMMIT:-unknown}" > $O/commit.txt
 ls -la $O | head -30
