@@ -458,6 +458,183 @@ __global__ __launch_bounds__(256, (RM == 1 && RN == 1) ? STCN_PW_WAVES : 1) void
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Pointwise CHAIN kernel: the ResNet-50 1x1 convs (conv1 / conv3 of every bottleneck, 2 - 32 K tiles) with dense [M][N] output.
+// The one-tile-per-workgroup instance above pays, per 64x64 tile, a prologue in which nothing computes (tile decode, two K tiles
+// of global loads before the first MFMA) and an epilogue - around as little as 2 K tiles of work (64 -> 256 of res2).  Here a
+// workgroup walks `nt` CONSECUTIVE tiles (n fastest: they share the activation rows in L2) as ONE software pipeline: the flattened
+// sequence of (tile, K tile) pairs is loaded two steps ahead exactly as above, so the first K tiles of tile j + 1 are already in
+// LDS / in flight while tile j finishes, its epilogue (residual requested a tile ahead, bias, ReLU, 16 row stores) runs between two
+// pipeline steps, and the grid is sized to ONE resident set of workgroups (4 per CU): no ragged last round, no tail split, no reduce.
+// Same staging layout, fragment reads, MFMA order and accumulation order as conv_gemm_kernel<2,2,1,1,false,RELU,true>: results are
+// bit-identical to it.
+template <bool RELU>
+__global__ __launch_bounds__(256, STCN_PW_WAVES) void pw_chain_kernel(const ConvP p, const int tiles_n, const int ntile, const int nt,
+                                                                     const TileDiv td) {
+    constexpr int BM = 64, BN = 64;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *As = smem;                  // [2][BM][LDT]
+    float *Bs = smem + 2 * BM * LDT;   // [2][BN][LDT]
+    const int nb = gridDim.x, q8 = nb >> 3, r8 = nb & 7, xcd = blockIdx.x & 7;
+    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + ((int)blockIdx.x >> 3);      // XCD-contiguous
+    const int tile0 = swz * nt, tile1 = min(ntile, tile0 + nt);
+    if (tile0 >= tile1) return;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int kc = t & 7, r0 = t >> 3;
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x0), 0, p.x0_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w), 0, p.w_bytes, 0x00020000);
+    const unsigned out_bytes = (unsigned)((long)p.M * p.N * 4);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.res ? p.res : p.y), 0, out_bytes, 0x00020000);
+    const int nkt = p.Kp / BK;
+
+    // ---- load stream: (l_tile, l_kt) walks the flattened sequence; past the last tile every offset is out of range (zeros)
+    unsigned aoff[2], woff[2];
+    int l_tile = tile0, l_kt = 0;
+    auto set_load_tile = [&](int tile) {
+        int tm, tn;
+        tile_to_mn(min(tile, ntile - 1), tiles_n, ntile, p.panel, td, tm, tn);
+        const bool live = tile < tile1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = tm * BM + r0 + 32 * i, n = tn * BN + r0 + 32 * i;
+            aoff[i] = live && m < p.M ? (unsigned)((m * p.c0 + kc * 4) * 4) : OOB;
+            woff[i] = live && n < p.N ? (unsigned)((n * p.Kp + kc * 4) * 4) : OOB;
+        }
+    };
+    set_load_tile(tile0);
+    f32x4 ra[2][2], rb[2][2];
+    int g_k = 0;                                       // byte offset of the K tile being loaded (set by g_step)
+    auto g_step = [&]() {                              // advance the load stream by one K tile
+        g_k = l_kt * (BK * 4);
+        if (++l_kt == nkt) { l_kt = 0; ++l_tile; }
+    };
+    auto g_next_tile = [&]() { if (l_kt == 0) set_load_tile(l_tile); };     // after the loads of the last K tile of a tile were issued
+    auto g_a = [&](int i, auto setc) {
+        constexpr int ST = decltype(setc)::value;
+        ra[ST][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, aoff[i] + (unsigned)g_k, 0, 0));
+    };
+    auto g_b = [&](int i, auto setc) {
+        constexpr int ST = decltype(setc)::value;
+        rb[ST][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, woff[i] + (unsigned)g_k, 0, 0));
+    };
+    float *const a_st = As + r0 * LDT + kc * 4;
+    float *const b_st = Bs + r0 * LDT + kc * 4;
+    auto s_a = [&](int i, int buf, auto setc) {
+        constexpr int ST = decltype(setc)::value;
+        f32x4 v = ra[ST][i];
+        if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *reinterpret_cast<f32x4 *>(a_st + (buf * BM + 32 * i) * LDT) = v;
+    };
+    auto s_b = [&](int i, int buf, auto setc) {
+        constexpr int ST = decltype(setc)::value;
+        *reinterpret_cast<f32x4 *>(b_st + (buf * BN + 32 * i) * LDT) = rb[ST][i];
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    auto gload_all = [&](auto setc) {
+        g_step();
+        g_a(0, setc); g_a(1, setc); g_b(0, setc); g_b(1, setc);
+        g_next_tile();
+    };
+
+    // ---- compute stream
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    int c_tile = tile0, k_left = nkt;
+    float rpre[16];
+    unsigned v0 = OOB;                                 // byte offset of (first row, column) of this lane's accumulator block; OOB: column >= N
+    const unsigned n4 = (unsigned)p.N * 4u;
+    float bv = 0.f;
+    auto tile_begin = [&](int tile) {                  // output coordinates of the tile, its bias and its residual block (in flight under the K loop)
+        int tm, tn;
+        tile_to_mn(tile, tiles_n, ntile, p.panel, td, tm, tn);
+        const int n0 = tn * BN + wn * 32 + (lane & 31), mb0 = tm * BM + wm * 32 + 4 * (lane >> 5);
+        v0 = n0 < p.N ? (unsigned)(((long)mb0 * p.N + n0) * 4) : OOB;
+        bv = p.bias && n0 < p.N ? p.bias[n0] : 0.f;
+        if (p.res) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                rpre[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, v0 + (unsigned)((r & 3) + 8 * (r >> 2)) * n4, 0, 0));
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rpre[r] = 0.f;
+        }
+    };
+    const float lo = p.relu_out ? 0.f : -__builtin_inff();
+    auto tile_end = [&]() {                            // epilogue of the finished tile; rows >= M lie beyond the descriptor range (dropped)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = fmaxf(acc[r] + bv + rpre[r], lo);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, v0 + (unsigned)((r & 3) + 8 * (r >> 2)) * n4, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        if (++c_tile < tile1) tile_begin(c_tile);
+    };
+
+    gload_all(I0{});
+    gload_all(I1{});
+    s_a(0, 0, I0{}); s_a(1, 0, I0{}); s_b(0, 0, I0{}); s_b(1, 0, I0{});
+    __syncthreads();
+    tile_begin(tile0);
+    const int arow = (wm * 32 + (lane & 31)) * LDT + (lane >> 5) * 4;
+    const int brow = (wn * 32 + (lane & 31)) * LDT + (lane >> 5) * 4;
+    // step `it`: C(it) from LDS buffer it & 1; G(it + 2) -> register set it & 1; S(it + 1) from the other set -> LDS buffer (it + 1) & 1
+    auto step = [&](auto gsc) {
+        constexpr int GS = decltype(gsc)::value;
+        using SS = std::integral_constant<int, GS ^ 1>;
+        constexpr int buf = GS;
+        const float *a_s = As + buf * BM * LDT + arow;
+        const float *b_s = Bs + buf * BN * LDT + brow;
+        f32x4 fa[2], fb[2];
+        fa[0] = *reinterpret_cast<const f32x4 *>(a_s);
+        fb[0] = *reinterpret_cast<const f32x4 *>(b_s);
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            const int cur = kb & 1;
+            if (kb < 3) {
+                fa[cur ^ 1] = *reinterpret_cast<const f32x4 *>(a_s + (kb + 1) * 8);
+                fb[cur ^ 1] = *reinterpret_cast<const f32x4 *>(b_s + (kb + 1) * 8);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][j], fb[cur][j], acc, 0, 0, 0);
+                const int slot = 4 * kb + j;
+                if (slot == 0) g_step();
+                else if (slot <= 2) g_a(slot - 1, gsc);
+                else if (slot <= 4) g_b(slot - 3, gsc);
+                else if (slot == 5) g_next_tile();
+                else if (slot >= 11 && slot < 13) s_a(slot - 11, buf ^ 1, SS{});
+                else if (slot >= 13 && slot < 15) s_b(slot - 13, buf ^ 1, SS{});
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+        if (--k_left == 0) { k_left = nkt; tile_end(); }
+    };
+    const int total = (tile1 - tile0) * nkt;
+    int it = 0;
+    for (; it + 1 < total; it += 2) {
+        step(I0{});
+        step(I1{});
+    }
+    if (it < total) step(I0{});
+}
+
+// tiles per workgroup of the chain kernel for this conv, or 0 when it does not apply (conv_plan decides; conv_launch follows p.chain)
+static int pw_chain_tiles(const ConvP &p, int force_splitk) {
+    if (!p.kn.pw_chain || force_splitk > 0 || !p.pointwise || !p.affine_out || p.N <= 32 || (p.Cin % 32) != 0) return 0;
+    const long ntile = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
+    static const int cus = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+    const long resident = (long)cus * STCN_PW_WAVES;                  // workgroups the chip holds at once (one wave per SIMD each)
+    if (ntile < resident + resident / 2) return 0;                    // up to 1.5 resident sets: the one-tile instance (with its tail balancing) is as good
+    const long nt = (ntile + resident - 1) / resident;
+    return (int)(nt > 16 ? 16 : nt);
+}
+
 // y = sum_s partial[s] + bias (+res) (relu); 4 columns per thread
 __global__ __launch_bounds__(256) void conv_reduce_kernel(const ConvP p) {
     const long total4 = (long)p.M * p.N / 4;
@@ -581,6 +758,8 @@ void conv_plan(ConvP &p, int force_splitk, size_t ws_floats) {
     p.panel = panel_env;
     p.tile_big = pl.big; p.splitk = pl.splitk;
     p.rem_full = pl.rem_full; p.rem_split = pl.rem_split; p.rem_per = pl.rem_per;
+    p.chain = pw_chain_tiles(p, force_splitk);
+    if (p.chain) { p.tile_big = 0; p.splitk = 1; p.rem_full = p.rem_split = p.rem_per = 0; }      // whole tiles, walked nt at a time
     static const bool dbg = getenv("STCN_CONV_PLAN_DEBUG") != nullptr;
     if (dbg)
         fprintf(stderr, "conv_plan M=%d N=%d K=%d: %s splitk=%d tail=(%d full, %d pieces of %d) cost %.0f\n", p.M, p.N, p.Kp,
@@ -603,6 +782,7 @@ void allow_big_lds(const void *kernel, size_t lds) {
 // which instance conv_launch takes for this (planned) conv - reported to the tests through stcn_last_conv_path()
 const char *conv_variant_name(const ConvP &p) {
     const bool narrow = narrow_variant(p), big = p.tile_big != 0, smallc = smallc_variant(p);
+    if (p.chain) return "direct_pointwise_chain";
     if (p.pointwise && !big && !narrow && !smallc) return "direct_pointwise";
     if (big) return "direct_big";
     if (narrow) return smallc ? "direct_narrow_smallc" : "direct_narrow";
@@ -623,6 +803,17 @@ void conv_launch(const ConvP &p, hipStream_t s, hipEvent_t *ev_gemm, hipEvent_t 
     const int pn = p.panel;
     const TileDiv td{fastdiv_make((unsigned)ntile), fastdiv_make((unsigned)tiles_n), fastdiv_make((unsigned)(tiles_m * (pn > 0 ? pn : 1))), tiles_m};
     hipEvent_t e0 = ev_gemm ? ev_gemm[0] : nullptr, e1 = ev_gemm ? ev_gemm[1] : nullptr;
+    if (p.chain) {                                        // pointwise chain: nt consecutive tiles per workgroup, one resident set of workgroups
+        const dim3 cgrid((unsigned)((ntile + p.chain - 1) / p.chain));
+        if (p.relu_in) {
+            if (e0) hipExtLaunchKernelGGL(pw_chain_kernel<true>, cgrid, dim3(256), lds, s, e0, e1, 0, p, tiles_n, ntile, p.chain, td);
+            else hipLaunchKernelGGL(pw_chain_kernel<true>, cgrid, dim3(256), lds, s, p, tiles_n, ntile, p.chain, td);
+        } else {
+            if (e0) hipExtLaunchKernelGGL(pw_chain_kernel<false>, cgrid, dim3(256), lds, s, e0, e1, 0, p, tiles_n, ntile, p.chain, td);
+            else hipLaunchKernelGGL(pw_chain_kernel<false>, cgrid, dim3(256), lds, s, p, tiles_n, ntile, p.chain, td);
+        }
+        return;
+    }
     {
 #define STCN_LAUNCH(WM_, WN_, RM_, RN_, SC_, RL_, ...)                                                                  \
     do {                                                                                                                 \

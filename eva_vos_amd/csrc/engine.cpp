@@ -4,6 +4,7 @@
 #include "engine.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -33,6 +34,7 @@ Knobs Knobs::from_env() {
     k.wino4_chunk_mb = geti("STCN_WINO4_CHUNK_MB", k.wino4_chunk_mb);
     k.fusion_conv12 = geti("STCN_FUSION_CONV12", k.fusion_conv12) != 0;
     k.fusion_wino = geti("STCN_FUSION_WINO", k.fusion_wino) != 0;
+    k.pw_chain = geti("STCN_PW_CHAIN", k.pw_chain) != 0;
     return k;
 }
 
@@ -443,7 +445,7 @@ void Work::release() {
 // fault injection for tests (stcn_test_fail_at): the n-th launch_status() call of this thread reports a failure
 static thread_local int g_fail_countdown = 0;
 static thread_local int g_fail_reserve = 0;      // tests (stcn_test_fail_at(-1)): the next up-front bank reservation of this thread fails
-static int g_side_delay_us = 0;          // tests (stcn_test_side_delay_us): every offloaded FusionNet group starts this much later
+static std::atomic<int> g_side_delay_us{0};   // tests (stcn_test_side_delay_us): every offloaded FusionNet group starts this much later
 void inject_failure_after(int n) { g_fail_countdown = n; }
 int launch_status(const char *what) {
     if (g_fail_countdown > 0 && --g_fail_countdown == 0) {
@@ -1269,7 +1271,7 @@ static int do_pass(stcn_engine *e, int idx, bool forward) {
                 if (off && g == 0) {                           // (groups decode in one pass: every agg of the group is final here)
                     HIPCHK(hipEventRecord(e->ev_dec[e->agg_buf], e->stream));
                     HIPCHK(hipStreamWaitEvent(e->side, e->ev_dec[e->agg_buf], 0));
-                    if (g_side_delay_us > 0) spin_launch(g_side_delay_us, e->side);      // tests: a slow side stream (stcn_test_side_delay_us)
+                    if (const int us = g_side_delay_us.load(std::memory_order_relaxed)) spin_launch(us, e->side);      // tests: a slow side stream (stcn_test_side_delay_us)
                 }
                 {
                     Scope sc(&e->prof, STCN_K_ATTENTION, fs, 2.0 * d.hw16 * d.hw16 * 64);
@@ -1392,7 +1394,7 @@ const char *stcn_last_conv_path(void) { return stcn::last_conv_path(); }
 
 // test hook: delays the side stream by `us` microseconds in front of every offloaded FusionNet group (0: off).  Makes the
 // orderings between the two streams that are only enforced by events observable: a missing wait shows up as a wrong result
-int stcn_test_side_delay_us(int us) { g_side_delay_us = us < 0 ? 0 : us; return STCN_OK; }
+int stcn_test_side_delay_us(int us) { g_side_delay_us.store(us < 0 ? 0 : us, std::memory_order_relaxed); return STCN_OK; }
 
 // test hook: the n-th launch-status check of the calling thread (counted from now) reports an injected failure
 int stcn_test_fail_at(int n) {

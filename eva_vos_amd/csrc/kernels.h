@@ -37,6 +37,7 @@ struct Knobs {
     int wino4_chunk_mb = 160;   // STCN_WINO4_CHUNK_MB: V bytes per slice of a chunked F(4x4) launch (0: unchunked)
     int fusion_conv12 = 0;      // STCN_FUSION_CONV12: FusionNet conv1 on the direct FusionNet kernel
     int fusion_wino = 1;        // STCN_FUSION_WINO: FusionNet convs as Winograd F(2x2) inside the workgroup
+    int pw_chain = 0;           // STCN_PW_CHAIN: large pointwise convs on the chain kernel (several tiles per workgroup, one pipeline)
     static Knobs from_env();
 };
 
@@ -75,6 +76,7 @@ struct ConvP {
     int affine_out;         // y (and res, if any) are dense [M][N]: element (m, n) at (m * N + n) * 4 bytes, < 4 GiB
     int tile_big;           // 1 = 128x128 workgroup tiles (fp32 kernel)
     int panel;              // > 0: tiles are walked in panels of this many n-tiles (fp32 kernel)
+    int chain;              // > 0: pointwise chain kernel, this many consecutive tiles per workgroup (conv_plan)
     Knobs kn;               // the workspace's snapshot of the launch-level tunables
 };
 // fills the launch plan of p (tile variant, split-K or tail balancing); force_splitk > 0 pins a plain split-K;

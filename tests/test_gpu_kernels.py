@@ -138,6 +138,50 @@ def test_conv_matches_fp64_reference(B, H, W, Cin, Cout, K, s, flags, splitk, pa
             assert "chunks=2" in ran, ran
 
 
+#                B  H    W    Cin  Cout flags  (1x1 convs large enough for the chain kernel: >= 1536 tiles of 64x64)
+CHAIN_CASES = [(5, 120, 216, 64, 256, 2),      # res2 conv3: 2 K tiles per tile, 8100 tiles, residual + ReLU
+               (5, 120, 216, 256, 64, 2),      # res2 conv1: one n-tile per row block - consecutive tiles walk down M
+               (5, 60, 108, 128, 512, 2),      # layer2 conv3
+               (2, 97, 131, 96, 192, 3),       # odd K-tile count (3), 3 n-tiles (no panels), ragged M, ReLU on the input
+               (3, 111, 120, 32, 320, 0),      # ONE K tile per tile, 5 n-tiles
+               (1, 200, 333, 160, 100, 2)]     # N not a multiple of 64 (ragged last n-tile), 5 K tiles
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,flags", CHAIN_CASES)
+def test_pointwise_chain_kernel_equals_the_one_tile_instance(B, H, W, Cin, Cout, flags, monkeypatch):
+    """pw_chain_kernel (several consecutive 64x64 tiles per workgroup as ONE software pipeline, STCN_PW_CHAIN=1) against fp64 and -
+    same staging, MFMA and accumulation order - BIT-identical to the one-tile pointwise instance; with and without a residual."""
+    g = torch.Generator().manual_seed(B * 7 + H * 13 + Cin + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) * (2.0 / Cin) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    res = torch.randn(B, Cout, H, W, generator=g)
+    for use_res in (True, False):
+        ref = F.conv2d((F.relu(x) if flags & 1 else x).double(), w.double(), b.double())
+        if use_res:
+            ref = ref + res.double()
+        if flags & 2:
+            ref = F.relu(ref)
+        outs = []
+        for chain in ("0", "1"):
+            monkeypatch.setenv("STCN_PW_CHAIN", chain)
+            y = torch.full((B, H, W, Cout), float("nan"), device="cuda")
+            call("stcn_test_conv", stream(), nhwc(x), dev(w.permute(0, 2, 3, 1)), dev(b), nhwc(res) if use_res else None, y,
+                 B, H, W, Cin, Cout, 1, 1, 1, 0, flags, 0)
+            assert last_path().startswith("direct_pointwise_chain" if chain == "1" else "direct_pointwise "), last_path()
+            outs.append(y.cpu())
+            if chain == "0":
+                tail = "+tail" in last_path()        # the one-tile plan cut its last tiles into K pieces: another summation order there
+        got = outs[1].permute(0, 3, 1, 2).double()
+        assert torch.isfinite(got).all()
+        err = (got - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 2e-5, err
+        if tail:
+            assert (outs[0] - outs[1]).abs().max().item() <= 2e-6 * ref.abs().max().item()
+        else:
+            assert torch.equal(outs[0], outs[1]), "the chain kernel must reproduce the one-tile instance bit for bit"
+
+
 def _random_conv_cases():
     """Seeded sweep over the shapes the fixed list cannot enumerate: every Winograd / FusionNet / direct instance under random
     sizes (ragged tile rows and columns, padded workgroup tiles), batch, residual and ReLU combinations."""
