@@ -142,7 +142,7 @@ def test_conv_matches_fp64_reference(B, H, W, Cin, Cout, K, s, flags, splitk, pa
 CHAIN_CASES = [(5, 120, 216, 64, 256, 2),      # res2 conv3: 2 K tiles per tile, 8100 tiles, residual + ReLU
                (5, 120, 216, 256, 64, 2),      # res2 conv1: one n-tile per row block - consecutive tiles walk down M
                (5, 60, 108, 128, 512, 2),      # layer2 conv3
-               (2, 97, 131, 96, 192, 3),       # odd K-tile count (3), 3 n-tiles (no panels), ragged M, ReLU on the input
+               (3, 97, 131, 96, 192, 3),       # odd K-tile count (3), 3 n-tiles (no panels), ragged M, ReLU on the input
                (3, 111, 120, 32, 320, 0),      # ONE K tile per tile, 5 n-tiles
                (1, 200, 333, 160, 100, 2)]     # N not a multiple of 64 (ragged last n-tile), 5 K tiles
 
