@@ -16,6 +16,8 @@ Output: ONE JSON line on rank 0 (see the task contract) with two extra objects:
                  fp32 MFMA peak 157.3 TFLOP/s (MI355X_MICROARCH.md).
   cpu_baseline - the CPU oracle (oracle/stcn_oracle.py, a port validated against the reference) timed on
                  this box's host cores on a bounded sample of BASELINE config 1 (both rounds), rank 0 at N=1 only.
+Parity legs in the same line (CPU oracle AND HIP engine on the same inputs): parity_vs_cpu_oracle (BASELINE config 1: T=82, two rounds), parity_long_clip
+(T=104), parity_session (8 rounds of the reference's oracle mask policy at 480p), config3.parity_vs_cpu_oracle (k=5, all pixels, multi-object recipe).
 Further objects (not the headline): roofline_memread (the space-time memory read at config-3 scale, MFMA fraction on
 2*N*Q*64 and GB/s on SURVEY 8(d)'s algorithmic bytes), config3 (k=5, mem_freq=1, T=104: the full-bank multi-object
 case), roofline_r2 (a second interaction: cached keys + fusion), davis_val (30 DAVIS-val lengths, LPT over ranks).  Real data: when ./model_weights/mivos/{stcn,fusion}.pth and
