@@ -40,6 +40,7 @@ PROTOTYPES = {
     "stcn_model_destroy": (_I, [_P]),
     "stcn_engine_create": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, C.POINTER(_P)]),
     "stcn_engine_create_ex": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, C.POINTER(EngineOpts), C.POINTER(_P)]),
+    "stcn_engine_get_opts": (_I, [_P, C.POINTER(EngineOpts)]),
     "stcn_engine_destroy": (_I, [_P]),
     "stcn_engine_reset": (_I, [_P]),
     "stcn_engine_clone": (_I, [_P, _P, _P, _P, C.POINTER(_P)]),

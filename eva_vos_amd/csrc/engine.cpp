@@ -1403,6 +1403,16 @@ int stcn_test_fail_at(int n) {
     return STCN_OK;
 }
 
+// the engine's RESOLVED tunables (explicit option, else environment at create, else default; clipped as engine_alloc_common clips them)
+int stcn_engine_get_opts(const stcn_engine *e, stcn_engine_opts *out) {
+    if (!e || !out) return STCN_E_INVALID;
+    out->lookahead = e->lookahead;
+    out->decode_batch = e->group;
+    out->key_batch = e->key_batch;
+    out->fuse_side = e->fuse_side ? 1 : 0;
+    return STCN_OK;
+}
+
 int stcn_get_stats(const stcn_engine *e, stcn_stats *out) {
     if (!e || !out) return STCN_E_INVALID;
     *out = e->stats;

@@ -238,6 +238,12 @@ class InferenceCore:
         _lib.check(_lib.lib().stcn_get_stats(self._engine, C.byref(s)))
         return {n: getattr(s, n) for n, _ in _lib.Stats._fields_}
 
+    def engine_options(self) -> dict:
+        """The tunables the engine runs with (explicit ``engine_options``, else STCN_* environment at construction, else defaults; clipped)."""
+        o = _lib.EngineOpts()
+        _lib.check(_lib.lib().stcn_engine_get_opts(self._engine, C.byref(o)))
+        return {n: getattr(o, n) for n, _ in _lib.EngineOpts._fields_}
+
     def set_profiling(self, on: bool) -> None:
         _lib.check(_lib.lib().stcn_engine_set_profiling(self._engine, 1 if on else 0))
 

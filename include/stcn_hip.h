@@ -85,6 +85,9 @@ typedef struct { int32_t lookahead, decode_batch, key_batch, fuse_side; } stcn_e
 int stcn_engine_create_ex(const stcn_model *m, int T, int H, int W, int k, int mem_freq,
                           void *stream, const float *images_dev, float *prob_dev, uint8_t *masks_dev,
                           const stcn_engine_opts *opts, stcn_engine **out);
+/* The values the engine actually runs with (after the environment / defaults were resolved and clipped: look-ahead is 0 when the
+ * clip is longer than the key cache, the decode group never exceeds mem_freq or 16 / k objects, fuse_side needs a fusion network). */
+int stcn_engine_get_opts(const stcn_engine *e, stcn_engine_opts *out);
 
 /* Back to the state right after stcn_engine_create (same clip): forgets interactions, certain memory and the
  * key-feature cache, re-initialises prob / masks.  Lets a driver reuse one engine's device memory for the

@@ -580,6 +580,31 @@ def test_a_slow_side_stream_cannot_corrupt_the_aggregate_buffers(nets, monkeypat
     assert torch.equal(outs[0][1], outs[1][1])
 
 
+def test_engine_options_are_explicit_per_engine_and_inherited_by_clones(nets, monkeypatch):
+    """The engine tunables travel through the ABI (stcn_engine_create_ex), not through os.environ: two engines of one process
+    with different options, an explicit option beats the environment, a clone keeps its source's resolved values whatever the
+    environment says at clone time, results do not depend on them, unknown names are refused."""
+    from mivos.inference_core import InferenceCore
+    T, H, W = 9, 112, 144
+    img, msk = synth.synthetic_clip(T, H, W, seed=21), synth.synthetic_mask(T, H, W, 1, seed=22)
+    monkeypatch.setenv("STCN_LOOKAHEAD", "2")
+    monkeypatch.setenv("STCN_DECODE_BATCH", "2")
+    a = InferenceCore(nets[0], nets[1], img, 1, mem_freq=3)
+    b = InferenceCore(nets[0], nets[1], img, 1, mem_freq=3, engine_options={"lookahead": 0, "decode_batch": 3, "key_batch": 2})
+    assert a.engine_options() == {"lookahead": 2, "decode_batch": 2, "key_batch": 4, "fuse_side": 1}
+    assert b.engine_options() == {"lookahead": 0, "decode_batch": 3, "key_batch": 2, "fuse_side": 0}      # no side stream at all
+    ra = [a.interact(msk[:, i], i).copy() for i in (1, 6)]
+    rb = [b.interact(msk[:, i], i).copy() for i in (1, 6)]
+    assert all(iou(x, y) >= 1 - 1e-3 for x, y in zip(ra, rb))          # another batching = another M of the same GEMMs: fp32 rounding only
+    monkeypatch.setenv("STCN_LOOKAHEAD", "0")
+    monkeypatch.setenv("STCN_DECODE_BATCH", "1")
+    c = copy.deepcopy(a)
+    assert c.engine_options() == a.engine_options()
+    assert np.array_equal(c.interact(msk[:, 4], 4), a.interact(msk[:, 4], 4))
+    with pytest.raises(TypeError, match="unknown engine_options"):
+        InferenceCore(nets[0], nets[1], img, 1, engine_options={"look_ahead": 0})
+
+
 def test_weight_snapshots_are_kept_per_fusion_net_and_data_writes_are_seen(weights):
     """Advisor items of round 2: (i) alternating two fusion networks with one propagation network must not rebuild the
     model every time (small LRU of snapshots); (ii) a whole-model update through ``.data`` (no version bump) is caught by
