@@ -13,7 +13,7 @@ SRC = os.path.join(ROOT, "gpurun_out", "prof_final")
 DST = os.path.join(ROOT, "profiles")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 commit = sys.argv[2] if len(sys.argv) > 2 else "unknown"      # the commit the GPU box ran (the snapshot has no .git)
-GEMM = ("conv_gemm_kernel", "wino_gemm_kernel", "wino4_gemm_kernel", "fusion_conv_kernel")   # the fp32-MFMA conv GEMMs (the roofline's dominant kernels)
+GEMM = ("conv_gemm_kernel", "pw_chain_kernel", "wino_gemm_kernel", "wino4_gemm_kernel", "fusion_conv_kernel")   # the fp32-MFMA conv GEMMs (the roofline's dominant kernels)
 
 
 def last_json(path):
@@ -61,7 +61,7 @@ lines = [f"# rocprofv3 --kernel-trace --stats - {tag}, final engine of the round
 for r in stats[:24]:
     lines.append(f"| {short(r['Name'])} | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.1f} | {float(r['AverageNs']) / 1e3:.1f} | {r['Percentage']} |")
 ex, al = roof["executed_flop_per_launch_avg"], roof["algorithmic_flop_per_launch_avg"]
-lines += ["", f"Conv GEMMs (conv_gemm_kernel all variants + wino_gemm_kernel + wino4_gemm_kernel): {calls} launches, {ns / 1e6:.1f} ms, average {ns / calls / 1e3:.2f} us per launch; "
+lines += ["", f"Conv GEMMs (conv_gemm_kernel all variants + pw_chain_kernel + wino_gemm_kernel + wino4_gemm_kernel): {calls} launches, {ns / 1e6:.1f} ms, average {ns / calls / 1e3:.2f} us per launch; "
           f"with {ex / 1e9:.3f} GFLOP executed / {al / 1e9:.3f} GFLOP algorithmic per launch on average (bench roofline leg) = "
           f"{ex / (ns / calls * 1e-9) / 1e12:.1f} TFLOP/s executed on the matrix cores.",
           f"Including the Winograd input transforms ({wi_ns / 1e6:.1f} ms) and split-K reduces ({rd_ns / 1e6:.1f} ms): "
