@@ -462,7 +462,7 @@ __global__ __launch_bounds__(256, (RM == 1 && RN == 1) ? STCN_PW_WAVES : 1) void
 // Pointwise CHAIN kernel: the ResNet-50 1x1 convs (conv1 / conv3 of every bottleneck, 2 - 32 K tiles) with dense [M][N] output.
 // The one-tile-per-workgroup instance above pays, per 64x64 tile, a prologue in which nothing computes (tile decode, two K tiles
 // of global loads before the first MFMA) and an epilogue - around as little as 2 K tiles of work (64 -> 256 of res2).  Here a
-// workgroup walks `nt` CONSECUTIVE tiles (n fastest: they share the activation rows in L2) as ONE software pipeline: the flattened
+// workgroup walks `nt` tiles (strided over the grid, see below) as ONE software pipeline: the flattened
 // sequence of (tile, K tile) pairs is loaded two steps ahead exactly as above, so the first K tiles of tile j + 1 are already in
 // LDS / in flight while tile j finishes, its epilogue (residual requested a tile ahead, bias, ReLU, 16 row stores) runs between two
 // pipeline steps, and the grid is sized to ONE resident set of workgroups (4 per CU): no ragged last round, no tail split, no reduce.
@@ -477,7 +477,14 @@ __global__ __launch_bounds__(256, STCN_PW_WAVES) void pw_chain_kernel(const Conv
     float *Bs = smem + 2 * BM * LDT;   // [2][BN][LDT]
     const int nb = gridDim.x, q8 = nb >> 3, r8 = nb & 7, xcd = blockIdx.x & 7;
     const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + ((int)blockIdx.x >> 3);      // XCD-contiguous
-    const int tile0 = swz * nt, tile1 = min(ntile, tile0 + nt);
+    // tile walk of this workgroup: tile0, tile0 + tstep, ... (< tile1).  Consecutive (p.kn.pw_chain == 1): nt neighbouring tiles - the
+    // workgroup re-reads its own activation rows, which the residual / output streams of the 127 other workgroups of the XCD have
+    // pushed out of the 4 MB L2 by then (FETCH_SIZE of the class +22 %).  Strided (default): in step j the grid as a whole covers the
+    // contiguous band [j G, (j + 1) G) of tiles, exactly as the resident set of a one-tile launch does: the sibling n-tiles of an
+    // activation block run side by side on one XCD and share it in L2.
+    const bool strided = p.kn.pw_chain != 1;
+    const int tile0 = strided ? swz : swz * nt, tstep = strided ? nb : 1;
+    const int tile1 = strided ? ntile : min(ntile, tile0 + nt);
     if (tile0 >= tile1) return;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -508,7 +515,7 @@ __global__ __launch_bounds__(256, STCN_PW_WAVES) void pw_chain_kernel(const Conv
     int g_k = 0;                                       // byte offset of the K tile being loaded (set by g_step)
     auto g_step = [&]() {                              // advance the load stream by one K tile
         g_k = l_kt * (BK * 4);
-        if (++l_kt == nkt) { l_kt = 0; ++l_tile; }
+        if (++l_kt == nkt) { l_kt = 0; l_tile += tstep; }
     };
     auto g_next_tile = [&]() { if (l_kt == 0) set_load_tile(l_tile); };     // after the loads of the last K tile of a tile were issued
     auto g_a = [&](int i, auto setc) {
@@ -572,7 +579,8 @@ __global__ __launch_bounds__(256, STCN_PW_WAVES) void pw_chain_kernel(const Conv
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-        if (++c_tile < tile1) tile_begin(c_tile);
+        c_tile += tstep;
+        if (c_tile < tile1) tile_begin(c_tile);
     };
 
     gload_all(I0{});
@@ -615,7 +623,7 @@ __global__ __launch_bounds__(256, STCN_PW_WAVES) void pw_chain_kernel(const Conv
         __syncthreads();
         if (--k_left == 0) { k_left = nkt; tile_end(); }
     };
-    const int total = (tile1 - tile0) * nkt;
+    const int total = ((tile1 - tile0 + tstep - 1) / tstep) * nkt;
     int it = 0;
     for (; it + 1 < total; it += 2) {
         step(I0{});

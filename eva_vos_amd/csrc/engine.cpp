@@ -34,7 +34,7 @@ Knobs Knobs::from_env() {
     k.wino4_chunk_mb = geti("STCN_WINO4_CHUNK_MB", k.wino4_chunk_mb);
     k.fusion_conv12 = geti("STCN_FUSION_CONV12", k.fusion_conv12) != 0;
     k.fusion_wino = geti("STCN_FUSION_WINO", k.fusion_wino) != 0;
-    k.pw_chain = geti("STCN_PW_CHAIN", k.pw_chain) != 0;
+    k.pw_chain = geti("STCN_PW_CHAIN", k.pw_chain);
     return k;
 }
 

@@ -37,7 +37,8 @@ struct Knobs {
     int wino4_chunk_mb = 160;   // STCN_WINO4_CHUNK_MB: V bytes per slice of a chunked F(4x4) launch (0: unchunked)
     int fusion_conv12 = 0;      // STCN_FUSION_CONV12: FusionNet conv1 on the direct FusionNet kernel
     int fusion_wino = 1;        // STCN_FUSION_WINO: FusionNet convs as Winograd F(2x2) inside the workgroup
-    int pw_chain = 1;           // STCN_PW_CHAIN: large pointwise convs on the chain kernel (several tiles per workgroup, one pipeline)
+    int pw_chain = 2;           // STCN_PW_CHAIN: large pointwise convs on the chain kernel (several tiles per workgroup, one pipeline): 0 off,
+                                // 1 consecutive tiles per workgroup, 2 tiles strided over the grid (default)
     static Knobs from_env();
 };
 

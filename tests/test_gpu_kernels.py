@@ -163,15 +163,16 @@ def test_pointwise_chain_kernel_equals_the_one_tile_instance(B, H, W, Cin, Cout,
         if flags & 2:
             ref = F.relu(ref)
         outs = []
-        for chain in ("0", "1"):
+        for chain in ("0", "1", "2"):          # one tile per workgroup / consecutive tiles / tiles strided over the grid (default)
             monkeypatch.setenv("STCN_PW_CHAIN", chain)
             y = torch.full((B, H, W, Cout), float("nan"), device="cuda")
             call("stcn_test_conv", stream(), nhwc(x), dev(w.permute(0, 2, 3, 1)), dev(b), nhwc(res) if use_res else None, y,
                  B, H, W, Cin, Cout, 1, 1, 1, 0, flags, 0)
-            assert last_path().startswith("direct_pointwise_chain" if chain == "1" else "direct_pointwise "), last_path()
+            assert last_path().startswith("direct_pointwise_chain" if chain != "0" else "direct_pointwise "), last_path()
             outs.append(y.cpu())
             if chain == "0":
                 tail = "+tail" in last_path()        # the one-tile plan cut its last tiles into K pieces: another summation order there
+        assert torch.equal(outs[1], outs[2]), "the two tile walks of the chain kernel compute the same tiles in the same order of arithmetic"
         got = outs[1].permute(0, 3, 1, 2).double()
         assert torch.isfinite(got).all()
         err = (got - ref).abs().max().item() / ref.abs().max().item()
