@@ -288,7 +288,7 @@ def config3_parity(prop, fuse, psd, fsd, T, H, W, k):
                decisive_pixel_fraction=float(dec[1:].mean()), mask_pixels_differing=int((got != ref).sum()),
                mask_pixels_differing_on_decisive=int(((got != ref) & dec).sum()), mask_pixels_total=int(got.size),
                object_pixels_per_frame_min=[int((ref[1:] == o).reshape(T - 1, -1).sum(1).min()) for o in range(1, k + 1)],
-               prob_abs_diff_p999=float(torch.quantile(d.flatten()[::7], 0.999)), prob_abs_diff_max=float(d.max()))
+               prob_abs_diff_p999=float(np.quantile(d.flatten()[::max(7, d.numel() // 8000000 + 1)].numpy(), 0.999)), prob_abs_diff_max=float(d.max()))
     ious, fmin, fwhere = [], 1.0, None
     for o in range(1, k + 1):
         a_, b_ = got == o, ref == o

@@ -267,6 +267,17 @@ __global__ void copy_rows_kernel(const float *__restrict__ src, long ss, float *
     const long c = i - r * n;
     dst[r * ds + c] = src[r * ss + c];
 }
+// two contiguous copies in one launch: a [na floats, multiple of 4] -> da, b [nb floats] -> db (bank insertion: key rows + |mk|^2)
+__global__ void copy2_kernel(const float *__restrict__ a, float *__restrict__ da, long na4, const float *__restrict__ b, float *__restrict__ db,
+                             long nb) {
+    const long i = blockIdx.x * 256L + threadIdx.x;
+    if (i < na4) reinterpret_cast<f32x4 *>(da)[i] = reinterpret_cast<const f32x4 *>(a)[i];
+    else if (i - na4 < nb) db[i - na4] = b[i - na4];
+}
+void copy2_launch(const float *a, float *da, long na, const float *b, float *db, long nb, hipStream_t s) {
+    hipLaunchKernelGGL(copy2_kernel, dim3(nblocks(na / 4 + nb)), dim3(256), 0, s, a, da, na / 4, b, db, nb);
+}
+
 void copy_rows_launch(const float *src, long src_stride, float *dst, long dst_stride, int rows, long n,
                       hipStream_t s) {
     hipLaunchKernelGGL(copy_rows_kernel, dim3(nblocks(rows * n)), dim3(256), 0, s, src, src_stride, dst, dst_stride,

@@ -699,7 +699,7 @@ int encode_value(const Model &m, Work &w, hipStream_t s, const float *img4, cons
 
 // Decoder (prop_net.py:13-30) on cat[readout, f16_thin] + sigmoid + aggregate_wbg
 int decode(const Model &m, Work &w, hipStream_t s, const float *readout, const float *f16_thin, const float *s8,
-           const float *s4, float *agg, long agg_stride, const float *dthin, const float *cthin, int G, long slot_bs) {
+           const float *s4, float *agg, long agg_stride, const float *dthin, const float *cthin, int G, long slot_bs, long agg_gs) {
     const Dims &d = w.d;
     const int k = w.k;
     if (G > 1 && (!dthin || !cthin)) { set_error("decode: frame batches need the cached frame parts"); return STCN_E_INVALID; }
@@ -733,7 +733,7 @@ int decode(const Model &m, Work &w, hipStream_t s, const float *readout, const f
     {
         Scope sc(w.prof, STCN_K_ELEMWISE, s);
         if (G > 1)                               // frame g: its k objects are G planes apart; agg [G][k+1][npix]; one launch for the group
-            up4_sigmoid_aggregate_launch(w.logit4, k, d.h4, d.w4, agg, agg_stride, s, (long)G * d.hw4, G, (long)d.hw4, (long)(k + 1) * agg_stride);
+            up4_sigmoid_aggregate_launch(w.logit4, k, d.h4, d.w4, agg, agg_stride, s, (long)G * d.hw4, G, (long)d.hw4, agg_gs ? agg_gs : (long)(k + 1) * agg_stride);
         else
             up4_sigmoid_aggregate_launch(w.logit4, k, d.h4, d.w4, agg, agg_stride, s);
     }
@@ -1122,8 +1122,10 @@ static float *bank_v_slot(stcn_engine *e, int slot) { return e->bank_v + (size_t
 // write key (from cache) + freshly encoded value of frame ti into bank slot `slot`
 static int bank_insert(stcn_engine *e, int slot, int ti, const SlotPtrs &kf, const float *masks, long mask_stride) {
     const Dims &d = e->d;
-    HIPCHK(hipMemcpyAsync(e->bank_k + (size_t)slot * d.hw16 * 64, kf.k16, (size_t)d.hw16 * 64 * 4, hipMemcpyDeviceToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(e->bank_msq + (size_t)slot * d.hw16, kf.msq, (size_t)d.hw16 * 4, hipMemcpyDeviceToDevice, e->stream));
+    {   // key rows + |mk|^2 of the frame into the bank: ONE small kernel (two hipMemcpyAsync cost 14 us of copy-kernel time each)
+        Scope sc(&e->prof, STCN_K_ELEMWISE, e->stream);
+        copy2_launch(kf.k16, e->bank_k + (size_t)slot * d.hw16 * 64, (long)d.hw16 * 64, kf.msq, e->bank_msq + (size_t)slot * d.hw16, d.hw16, e->stream);
+    }
     if (!e->vparts_ready[ti]) {
         RC(value_frame_parts(*e->model, e->work, e->stream, kf.f16, kf.vd, kf.vc));
         e->vparts_ready[ti] = 1;
@@ -1226,6 +1228,12 @@ static int do_pass(stcn_engine *e, int idx, bool forward) {
         }
         // agg of the frame at sweep position g lives at aggbuf + pos(g) * agg_fs
         auto pos = [&](int g) { return batched ? (ti + g * step) - t_lo : 0; };
+        // Unfused sweeps (first interactions, and the side of a later interaction that faces no earlier one): the aggregated
+        // probabilities ARE the output rows (inference_core.py:189) - the decoder's tail writes them straight into prob[:, t]
+        // (row stride = prob's, frame stride = one frame) instead of an aggregate buffer + one copy launch per frame
+        const bool direct = !fuse;
+        auto agg_of = [&](int g) { return direct ? e->prob + (size_t)(ti + g * step) * d.npix : aggbuf + (size_t)pos(g) * agg_fs; };
+        const long agg_rs = direct ? prs : (long)d.npix;      // floats between the k + 1 rows of a frame's aggregate
         if (batched) {
             const SlotPtrs &f0 = kf[forward ? 0 : G - 1];      // slot of frame t_lo
             {   // the group's queries, contiguous: one read of the bank serves G * hw16 queries
@@ -1240,23 +1248,23 @@ static int do_pass(stcn_engine *e, int idx, bool forward) {
                                    e->stream);
             }
             RC(launch_status("memory read (decode group)"));
-            RC(decode(*e->model, w, e->stream, w.readout, f0.f16_thin, f0.s8, f0.s4, aggbuf, d.npix, f0.dthin, f0.cthin, G,
-                      (long)e->slot_floats));
+            RC(decode(*e->model, w, e->stream, w.readout, f0.f16_thin, f0.s8, f0.s4, direct ? e->prob + (size_t)t_lo * d.npix : aggbuf, agg_rs, f0.dthin,
+                      f0.cthin, G, (long)e->slot_floats, direct ? (long)d.npix : 0));
         }
         // ---- per frame, in sweep order: (unbatched: read + decode,) bank insertion, fusion / output
         for (int g = 0; g < G; ++g) {
             const int t = ti + g * step;
             const SlotPtrs &f = kf[g];
-            float *agg = aggbuf + (size_t)pos(g) * agg_fs;
+            float *agg = agg_of(g);
             if (!batched) {
                 RC(read(f, w.readout));
                 dbg_sum(e, "k16", t, f.k16, (size_t)d.hw16 * 64);
                 dbg_sum(e, "readout", t, w.readout, (size_t)k * d.hw16 * 512);
-                RC(decode(*e->model, w, e->stream, w.readout, f.f16_thin, f.s8, f.s4, agg, d.npix, f.dthin, f.cthin));
+                RC(decode(*e->model, w, e->stream, w.readout, f.f16_thin, f.s8, f.s4, agg, agg_rs, f.dthin, f.cthin));
             }
-            dbg_sum(e, "agg", t, agg, (size_t)(k + 1) * d.npix);
+            if (!direct) dbg_sum(e, "agg", t, agg, (size_t)(k + 1) * d.npix);
             if (inserts(t)) {
-                RC(bank_insert(e, m_front, t, f, agg + d.npix, d.npix));
+                RC(bank_insert(e, m_front, t, f, agg + agg_rs, agg_rs));
                 ++m_front;
                 last_ti = t;
             }
@@ -1286,10 +1294,7 @@ static int do_pass(stcn_engine *e, int idx, bool forward) {
                 Scope sc(&e->prof, STCN_K_ELEMWISE, fs);
                 sigmoid_aggregate_launch(fw.flogit, k, d.npix, dst, prs, fs);
                 e->stats.fused++;
-            } else {
-                Scope sc(&e->prof, STCN_K_ELEMWISE, e->stream);
-                copy_rows_launch(agg, d.npix, dst, prs, k + 1, d.npix, e->stream);
-            }
+            }                                                  // (unfused: the decoder's tail wrote prob[:, t] itself)
             e->stats.frames++;
         }
         if (off) {                                                 // the side stream is done with this buffer when ev_fuse fires

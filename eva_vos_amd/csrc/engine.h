@@ -134,7 +134,7 @@ int value_frame_parts(const Model &m, Work &w, hipStream_t s, const float *f16, 
 // queries writes), agg [G][k+1][npix], the per-frame inputs of frame g at <ptr> + g * slot_bs (consecutive key-cache slots)
 int decode(const Model &m, Work &w, hipStream_t s, const float *readout, const float *f16_thin,
            const float *s8, const float *s4, float *agg, long agg_stride, const float *dthin = nullptr,
-           const float *cthin = nullptr, int G = 1, long slot_bs = 0);
+           const float *cthin = nullptr, int G = 1, long slot_bs = 0, long agg_gs = 0);      // agg_gs: floats between the agg blocks of consecutive frames (0: (k + 1) * agg_stride)
 int fusion_logit(const Model &m, Work &w, hipStream_t s, const float *img4, const float *prev,
                  const float *curr, const float *attn2, float nc, float nr, float *logit);
 

@@ -145,6 +145,8 @@ void fill_launch(float *p, float v, long n, hipStream_t s);
 void spin_launch(int us, hipStream_t s);        // test aid: one wave that keeps stream s busy for `us` microseconds
 void copy_rows_launch(const float *src, long src_stride, float *dst, long dst_stride, int rows, long n,
                       hipStream_t s);
+// a [na floats, na % 4 == 0] -> da and b [nb floats] -> db in one launch
+void copy2_launch(const float *a, float *da, long na, const float *b, float *db, long nb, hipStream_t s);
 // interaction mask handling (inference_core.py:220-226): pads mask [mc,H,W] into [mc,nh,nw] planes,
 // writes pos/neg = clamp(+-(mask - prob[:,idx])) for all kk rows, then prob[:,idx] = mask (broadcast)
 void interact_mask_launch(const float *mask, int mc, int H, int W, int nh, int nw, int lw, int lh,
