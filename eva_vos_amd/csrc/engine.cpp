@@ -144,9 +144,12 @@ int make_wino4(Model &m, ConvW &cw, const std::vector<float> &w) {
 
 // F(4x4,3x3) is reserved for layers whose outputs become probabilities or memory VALUES, never the keys that decide top-50
 // membership: the decoder proper with its frame-only skip / compress convs, key_comp (f16_thin only feeds the decoder) and the
-// value encoder's fuser.  The ResNet trunks and key_proj stay on F(2x2) / direct kernels
+// value encoder (fuser and, round 4, its ResNet-18 trunk).  The KEY encoder's trunk and key_proj stay on F(2x2) / direct kernels
 static bool decoder_layer(const std::string &name) {
-    return name.compare(0, 8, "decoder.") == 0 || name == "key_comp" || name.compare(0, 20, "value_encoder.fuser.") == 0;
+    // round 4: also the value encoder's ResNet-18 trunk (its 128- and 256-channel stride-1 3x3 convs): everything in the value encoder
+    // ends in memory VALUES; at batch 1 these layers are small launches, which F(4x4) now covers by cutting every tile into K pieces
+    return name.compare(0, 8, "decoder.") == 0 || name == "key_comp" || name.compare(0, 20, "value_encoder.fuser.") == 0 ||
+           name.compare(0, 19, "value_encoder.layer") == 0;
 }
 
 static int add_convs(Model &m, const std::map<std::string, HostT> &sd) {

@@ -447,6 +447,27 @@ static int wino4_mode() {          // 0 off, 1 on for flagged layers with enough
     return m;
 }
 
+static int wino4_cus() {
+    static const int cus = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+    return cus;
+}
+
+// Small launches (round 4): a layer whose 32-tile workgroups do not even fill HALF a round of CUs - the value encoder's fuser and
+// its frame parts at batch 1 (1620 pixels x 512 channels = 64 workgroups), the 1/16-scale decoder layers of a single frame - used
+// to fall back to F(2x2) with split-K (threshold STCN_WINO4_MIN_WG).  The K pieces of the tail split generalise: EVERY tile is cut
+// into up to 8 pieces of >= 8 k-blocks so that about one round of CUs is busy, the output-domain partial sums meet in
+// wino4_reduce_kernel.  Returns the pieces per tile (1: leave the launch alone).
+static int wino4_small_pieces(int grid, int KB) {
+    static const bool on = [] { const char *e = getenv("STCN_WINO4_SMALL"); return !e || atoi(e) != 0; }();
+    const int cus = wino4_cus();
+    if (!on || grid * 2 > cus) return 1;
+    int sp = cus / grid;
+    sp = sp > 8 ? 8 : sp;
+    while (sp > 1 && KB / sp < 8) --sp;
+    const int per = (KB + sp - 1) / sp;
+    return (KB + per - 1) / per;
+}
+
 // floats of V workspace the F(4x4) path needs for this conv (0: not eligible).  min_wg: fewest workgroups worth launching
 size_t wino4_workspace_floats(const ConvP &p, int min_wg) {
     if (!wino4_mode() || !p.wino4_u || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.x1) return 0;
@@ -456,7 +477,9 @@ size_t wino4_workspace_floats(const ConvP &p, int min_wg) {
     if (36L * p.Cin * Mt_pad * 4 >= (1L << 32)) return 0;                   // 32-bit buffer offsets
     if ((long)p.B * (p.y_bs ? p.y_bs : (long)p.OH * p.OW * p.N) * 4 >= (1L << 32)) return 0;
     if (p.res && (long)(p.res_bmod ? p.res_bmod : p.B) * p.res_bs * 4 >= (1L << 32)) return 0;
-    if (wino4_mode() < 2 && (Mt_pad / W4T) * (p.N / W4N) < min_wg) return 0;  // too few workgroups: F(2x2) with its split-K is better
+    long wgs = (Mt_pad / W4T) * (p.N / W4N);
+    if (wgs * 2 <= wino4_cus()) wgs *= wino4_small_pieces((int)wgs, p.Cin / 8);   // a small launch is cut into K pieces (wino4_plan)
+    if (wino4_mode() < 2 && wgs < min_wg) return 0;                          // still too few workgroups: F(2x2) with its split-K is better
     return (size_t)36 * p.Cin * Mt_pad;
 }
 
@@ -465,7 +488,7 @@ struct W4Plan { int Mt, Mt_pad, tiles_m, tiles_n, mb, grid, full_wg, pieces, per
 static W4Plan wino4_plan(const ConvP &p, size_t slab_floats) {
     static const int mb_env = [] { const char *e = getenv("STCN_WINO4_MB"); return e ? atoi(e) : 0; }();
     static const bool tail_on = [] { const char *e = getenv("STCN_WINO4_TAIL"); return !e || atoi(e) != 0; }();
-    static const int cus = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+    const int cus = wino4_cus();
     W4Plan pl{};
     const int TH = (p.OH + 3) / 4, TW = (p.OW + 3) / 4, KB = p.Cin / 8;
     pl.Mt = p.B * TH * TW;
@@ -492,6 +515,14 @@ static W4Plan wino4_plan(const ConvP &p, size_t slab_floats) {
                 pl.full_wg = full; pl.pieces = sp; pl.per = per;
                 pl.grid = full + rem * sp;
             }
+        }
+    }
+    // Small launches: every tile in K pieces (see wino4_small_pieces)
+    if (tail_on && pl.mb == 1 && p.partial && pl.pieces == 1 && pl.grid * 2 <= cus) {
+        const int sp = wino4_small_pieces(pl.grid, KB);
+        if (sp > 1 && (size_t)pl.grid * sp * W4T * 16 * W4N <= slab_floats) {
+            pl.full_wg = 0; pl.pieces = sp; pl.per = (KB + sp - 1) / sp;
+            pl.grid *= sp;
         }
     }
     // Chunked launches (64-tile workgroups): V of the 1/4-scale decoder layers over a 5-frame group is 299 MB - written by the

@@ -58,6 +58,12 @@ CONVS = [
     # ... and its chunked launches (transform / GEMM alternate over slices of whole rounds): 408 workgroups of 64 tiles, run a
     # second time under STCN_WINO4_CHUNK_MB=1 = two slices (32 + 19 tile blocks)
     (2, 120, 216, 128, 256, 3, 1, 7, 0),
+    # ... and its SMALL launches: fewer workgroups than half a round of CUs - EVERY tile is cut into K pieces (the value encoder's fuser and
+    # frame parts at batch 1: 1620 pixels x 512 channels = 64 workgroups x 4 pieces; one decoder frame at 1/8 scale: 104 x 2)
+    (1, 30, 54, 1024, 512, 3, 1, 4, 0),
+    (1, 30, 54, 256, 512, 3, 1, 7, 0),
+    (2, 30, 54, 512, 512, 3, 1, 6, 0),      # batch 2 with a residual: 128 workgroups x 2 pieces
+    (1, 60, 108, 512, 256, 3, 1, 5, 0),
     # pointwise instance (1x1, stride 1): ragged M, residual + ReLU, split-K, and the stride-2 1x1 that must NOT take it
     (2, 19, 21, 256, 192, 1, 1, 2, 0),
     (1, 30, 54, 512, 128, 1, 1, 0, 3),
@@ -76,6 +82,7 @@ PATHS = [
     "wino4", "wino4", "wino4", "wino4", "wino4", "wino4",
     "wino4 chunks=1 +tail", "wino4",
     "wino4",
+    "wino4 chunks=1 +tail", "wino4 chunks=1 +tail", "wino4 chunks=1 +tail", "wino4 chunks=1 +tail",
     "direct_pointwise", "direct_pointwise splitk=3", "direct splitk",
 ]
 

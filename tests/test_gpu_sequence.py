@@ -452,12 +452,15 @@ def test_the_3x3_convs_really_run_as_winograd(nets):
     assert 0.3 < ratio < 0.65, ratio           # 1 / 2.25 on the F(2x2) share, 1 / 4 on the F(4x4) share, 1 on the rest, + tile padding
 
 
-def test_multi_object_decode_groups_equal_the_frame_by_frame_path(nets, monkeypatch):
+def test_multi_object_decode_groups_equal_the_frame_by_frame_path(nets_multi, monkeypatch):
     """k = 3, mem_freq = 5: the frames between two bank insertions are decoded as ONE batch of objects x frames (per-frame
     tensors broadcast over the objects by a modulo batch index).  Same engine with STCN_DECODE_BATCH=1 (the reference's
-    loop order, prop_net.py:183-187 / inference_core.py:166-188) must give the same masks and, up to fp32 summation order of
-    differently shaped GEMMs, the same probabilities."""
-    T, H, W, k = 12, 128, 160, 3
+    loop order, prop_net.py:183-187 / inference_core.py:166-188) must give the same masks and, up to fp32 rounding of
+    differently shaped launches (other GEMM shapes; single frames run the 1/16-scale layers as F(4x4) in K pieces), the same
+    probabilities.  Under the MULTI-OBJECT recipe at 240x432 (99.6 % decisive pixels in the oracle): with the plain recipe only
+    52-67 % of a 128x160 frame carry a well-conditioned label and the 1e-3 below was a matter of luck."""
+    nets = nets_multi
+    T, H, W, k = 12, 240, 432, 3
     img, msk = synth.synthetic_clip(T, H, W, seed=3), synth.synthetic_mask(T, H, W, k, seed=4)
     m0 = torch.cat([1 - msk[:, 0].sum(0, keepdim=True).clamp(0, 1), msk[:, 0]], 0)
     m7 = torch.cat([1 - msk[:, 7].sum(0, keepdim=True).clamp(0, 1), msk[:, 7]], 0)

@@ -39,6 +39,10 @@ SHAPES = [
     ("dec 3x3 256->256 @4",       1, 120, 216, 256,  256, 3, 1, 2),
     ("val.stem 7x7s2 8->64",      1, 480, 864, 8,    64,  7, 2, 0.2),
     ("val.l1 3x3 64",             1, 120, 216, 64,   64,  3, 1, 0.8),
+    ("val.l2 3x3 128",            1, 60,  108, 128,  128, 3, 1, 0.6),
+    ("val.l3 3x3 256",            1, 30,  54,  256,  256, 3, 1, 0.6),
+    ("val.fuser#a 3x3 256->512",  1, 30,  54,  256,  512, 3, 1, 0.4),
+    ("val.frame 3x3 1024->512",   1, 30,  54,  1024, 512, 3, 1, 0.4),
     ("val.fuser 3x3 1280->512",   1, 30,  54,  1280, 512, 3, 1, 0.4),
     ("val.fuser 3x3 512->512",    1, 30,  54,  512,  512, 3, 1, 0.6),
     ("fuse 3x3 12->32",           1, 480, 864, 12,   32,  3, 1, 0),
