@@ -461,9 +461,10 @@ static int wino4_small_pieces(int grid, int KB) {
     static const bool on = [] { const char *e = getenv("STCN_WINO4_SMALL"); return !e || atoi(e) != 0; }();
     const int cus = wino4_cus();
     if (!on || grid * 2 > cus) return 1;
+    static const int min_kb = [] { const char *e = getenv("STCN_WINO4_SMALL_KB"); const int v = e ? atoi(e) : 8; return v < 1 ? 1 : v; }();   // k-blocks per piece, at least
     int sp = cus / grid;
     sp = sp > 8 ? 8 : sp;
-    while (sp > 1 && KB / sp < 8) --sp;
+    while (sp > 1 && KB / sp < min_kb) --sp;
     const int per = (KB + sp - 1) / sp;
     return (KB + per - 1) / per;
 }
