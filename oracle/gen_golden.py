@@ -263,6 +263,9 @@ FULL_CASES = {
     # oracle/fit_multi_pred.py) - the decoder separates the objects, > 99 % of the pixels carry a decisive label in the
     # reference's own output and its thread counts agree to a handful of pixels: parity is stated on ALL pixels.
     "seq480k5": dict(H=480, W=854, k=5, T=12, mem_freq=1, script=[(0, 0)], prob_stride=8, threads=(1, 4, 8), decisive_eps=1e-2, seed=2),
+    # the multi-object FUSION path at the BASELINE resolution from the reference: 3 objects, mem_freq = 3 (decode groups of 3), a second
+    # interaction at frame 5 with FusionNet + attention read on frames 1..4 (fuse_one_frame per object, inference_core.py:193-207)
+    "seq480k3": dict(H=480, W=854, k=3, T=8, mem_freq=3, script=[(0, 0), (5, 5)], prob_stride=8, threads=(1, 4, 8), decisive_eps=1e-2, seed=2),
 }
 STAGE_CASES = {
     "stA": dict(H=128, W=160, k=1),
