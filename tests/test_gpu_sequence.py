@@ -66,7 +66,7 @@ def nets_of(g, tag, nets, weights):
     return (p.eval(), f.eval()), w
 
 
-@pytest.mark.parametrize("tag", ["seqA", "seqA1", "seqB", "seqC", "seqD", "seq480", "seq480k5", "seq480k3"])
+@pytest.mark.parametrize("tag", ["seqA", "seqA1", "seqB", "seqC", "seqD", "seq480", "seq480L", "seq480k5", "seq480k3"])
 def test_sequences_match_reference_goldens(tag, nets, weights):
     """seqA1 = the seqA script under weight recipe seed 1, seq480k5 = BASELINE config 3's shape (480x854, 5 objects, every
     frame enters the bank), seq480k3 = three objects at 480p with a second, FUSED interaction (both under the multi-object recipe,
