@@ -299,6 +299,13 @@ int stcn_metrics_jf_counts(void *stream, const uint8_t *gt_dev, const uint8_t *p
     return STCN_OK;
 }
 
+int stcn_metrics_j_counts(void *stream, const uint8_t *gt_dev, const uint8_t *pred_dev, int T, int H, int W, int32_t *counts_dev) {
+    if (!gt_dev || !pred_dev || !counts_dev || T < 1 || H < 1 || W < 1) { set_error("stcn_metrics_j_counts: bad arguments"); return STCN_E_INVALID; }
+    jf_counts_launch(gt_dev, pred_dev, T, H, W, -1, nullptr, counts_dev, (hipStream_t)stream);       // radius < 0: intersection / union only
+    HIPCHK(hipGetLastError());
+    return STCN_OK;
+}
+
 int stcn_bench_mfma_rate(void *stream, int ms_target, float *tflops, float *ms_out) {
     if (!tflops || ms_target < 1 || ms_target > 2000) { set_error("stcn_bench_mfma_rate: bad arguments"); return STCN_E_INVALID; }
     hipStream_t s = (hipStream_t)stream;

@@ -47,7 +47,7 @@ def frame_quality(processor, gt_thw: torch.Tensor, interacted: List[int], metric
     gen = seg.clone()
     if interacted:
         gen[interacted] = gtb[interacted]
-    rows = metrics.sequence_scores_gpu(gtb, gen)
+    rows = metrics.sequence_scores_gpu(gtb, gen, j_only=metric == "j")      # the boundary measure only when it is asked for
     q = rows[:, 0 if metric == "j" else 2].copy()
     empty = (gtb.flatten(1).sum(1) == 0).cpu().numpy()
     mu = float(np.mean(q[~empty])) if (~empty).any() else float("nan")

@@ -191,7 +191,7 @@ def per_frame_j(processor, gt_dev: torch.Tensor, interacted: List[int]) -> tuple
     gen = seg.clone()
     if interacted:
         gen[interacted] = gtb[interacted]
-    rows = metrics.sequence_scores_gpu(gtb, gen)
+    rows = metrics.sequence_scores_gpu(gtb, gen, j_only=True)               # the FQ policy selects by J (interactions/mask.py:113-146)
     q = rows[:, 0].copy()
     q[(gtb.flatten(1).sum(1) == 0).cpu().numpy()] = NO_OBJECT
     return q, gen.to(torch.uint8)

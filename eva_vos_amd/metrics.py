@@ -81,10 +81,11 @@ def _scores_from_counts(c: np.ndarray) -> np.ndarray:
     return out
 
 
-def sequence_scores_gpu(gt, pred):
+def sequence_scores_gpu(gt, pred, j_only: bool = False):
     """J, F, J&F per frame on the GPU (HIP kernels behind ``stcn_metrics_jf_counts``).
     gt, pred: torch uint8/bool tensors [T,H,W] on the same cuda device (non-zero = object).
-    Returns float64 [T,3]; only the 6*T integer counts cross PCIe."""
+    Returns float64 [T,3]; only the 6*T integer counts cross PCIe.  ``j_only``: the region measure alone (``stcn_metrics_j_counts``:
+    no boundary maps, no disk matching) - column 0 is J, columns 1 and 2 are NaN."""
     import ctypes as C
 
     import torch
@@ -96,6 +97,13 @@ def sequence_scores_gpu(gt, pred):
     T, H, W = gt.shape
     with torch.cuda.device(gt.device):
         counts = torch.empty((T, 6), dtype=torch.int32, device=gt.device)
+        if j_only:
+            _lib.check(_lib.lib().stcn_metrics_j_counts(C.c_void_p(torch.cuda.current_stream().cuda_stream), C.c_void_p(gt.data_ptr()),
+                                                        C.c_void_p(pred.data_ptr()), T, H, W, C.c_void_p(counts.data_ptr())), "stcn_metrics_j_counts")
+            c = counts.cpu().numpy()
+            out = np.full((T, 3), np.nan)
+            out[:, 0] = np.where(c[:, 1] > 0, c[:, 0] / np.maximum(c[:, 1], 1), 0.0)
+            return out
         scratch = torch.empty((T * H * W,), dtype=torch.uint8, device=gt.device)
         _lib.check(_lib.lib().stcn_metrics_jf_counts(C.c_void_p(torch.cuda.current_stream().cuda_stream),
                                                      C.c_void_p(gt.data_ptr()), C.c_void_p(pred.data_ptr()), T, H, W,

@@ -241,6 +241,10 @@ int stcn_get_conv_regimes(stcn_engine *e, double *out /*[6]*/);
  * frame per round by eval_processor_metric (interactions/eval.py:50-79). */
 int stcn_metrics_jf_counts(void *stream, const uint8_t *gt_dev, const uint8_t *pred_dev, int T, int H, int W,
                            int32_t *counts_dev, uint8_t *scratch_dev);
+/* The region measure alone: counts_dev int32 [T,6] with columns 0 (intersection) and 1 (union) filled, the others zero; no scratch.
+ * What the oracle annotation policy needs per round (interactions/mask.py:113-146 selects the frame with the worst J; eval_processor_metric
+ * with metric='j', interactions/eval.py:27-81). */
+int stcn_metrics_j_counts(void *stream, const uint8_t *gt_dev, const uint8_t *pred_dev, int T, int H, int W, int32_t *counts_dev);
 
 #ifdef __cplusplus
 }

@@ -423,6 +423,8 @@ def test_gpu_j_and_f_equal_the_cpu_metrics_exactly():
         gt[1, :, :] = False                                          # n_gt == 0, n_fg > 0
         gt[2, -10:, -15:] = True                                     # object touching the last row / column
         got = metrics.sequence_scores_gpu(torch.from_numpy(gt).cuda(), torch.from_numpy(pr).cuda())
+        jonly = metrics.sequence_scores_gpu(torch.from_numpy(gt).cuda(), torch.from_numpy(pr).cuda(), j_only=True)
+        assert np.array_equal(jonly[:, 0], got[:, 0]) and np.isnan(jonly[:, 1:]).all()       # the J-only entry point: same counts
         for t in range(T):
             j, f = metrics.jaccard(gt[t], pr[t]), metrics.f_measure(gt[t], pr[t])
             assert got[t, 0] == j and got[t, 1] == f, (T, H, W, t, got[t], j, f)
