@@ -40,7 +40,7 @@ def test_prefetched_device_clips_equal_the_reference_dataset(tmp_path):
 
 def test_fq_writer_from_device_tensors_equals_the_reference_writer(tmp_path):
     """save_state_masks / save_rgb_frames with DEVICE inputs (the resizes run on the GPU; PNG encoding on host threads, as the
-    driver uses them): mask PNGs byte-exact, RGB within 1 LSB of util/fq_dataset.py's output."""
+    driver uses them): the mask PNGs decode to exactly the reference's images, RGB within 1 LSB of util/fq_dataset.py's output."""
     from concurrent.futures import ThreadPoolExecutor
     g = load_golden("driver")
     n, T, H, W = [int(v) for v in g["writer.gen_shape"]]
