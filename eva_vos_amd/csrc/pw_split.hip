@@ -1,0 +1,348 @@
+// pw_split.hip - EXPERIMENT, not on the product path (reached only through the stcn_probe_pw_split_* hooks of hooks.cpp and
+// tools/pw_split_probe.py): a pointwise (1x1) convolution y[M][N] = x[M][K] . w[N][K]^T with fp32 operands, computed on the bf16 matrix
+// pipe from a three-way split of every operand.
+//
+//   x = xh + xm + xl,  xh = bf16(x), xm = bf16(x - xh), xl = bf16(x - xh - xm)      (8 + 8 + 8 significand bits: the split is exact
+//   for all but a few fp32 values whose low bits fall between the pieces; |x - xh - xm - xl| <= 2^-26 |x|)
+//   x.w ~ xh.wh + xh.wm + xm.wh + xh.wl + xl.wh + xm.wm                              (the three dropped products are <= 2^-25 |x||w|)
+//
+// Every bf16 x bf16 product is exact in fp32 and v_mfma_f32_32x32x16_bf16 accumulates in fp32, so the result carries fp32-level error
+// (measured against fp64 next to the exact-fp32 kernel by the probe) at 6 bf16 MFMAs per 16 K = 192 cycles per 32x32x16 block, against
+// 8 x v_mfma_f32_32x32x2_f32 = 512 cycles: 2.67x the matrix rate of the fp32 pipe (MI355X_MICROARCH.md, matrix cores: f32 = 1/16 of bf16).
+// The sums are NOT those of the fp32 kernels (other rounding points), so this is a different arithmetic, not a faster schedule of the
+// same one - which is why it stays an experiment this round.
+//
+// Workgroup: 256 threads = 4 waves as 2 (M) x 2 (N); tile 128 pixels x 128 output channels; each wave 2 x 2 blocks of 32 x 32.
+// K in stages of 32: the x tile is split on the fly while it is staged (the weights are split once, stcn::pw_split_weights_launch),
+// one LDS buffer [3 planes][128 rows][32 k] bf16 per operand (48 KB together: up to three workgroups per CU), the next stage's global
+// loads in flight under the current stage's MFMAs.
+#include "kernels.h"
+
+namespace stcn {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static constexpr int SP_BM = 128, SP_BN = 128, SP_BK = 32;
+static constexpr int SP_PLANE = 128 * SP_BK;           // bf16 elements of one plane of one operand
+
+// byte offset of chunk c (8 bf16 = 16 B; 4 per 32-k row) of row r inside a plane: rows of 64 B, chunk slot swizzled so that the 16 lanes
+// of a ds_read_b128 / ds_write_b128 pass (16 consecutive rows, one chunk index) touch 16 different 16-byte bank groups
+// (ds_read_b128: banks mod 64 over the instruction's non-contiguous 16-lane groups); the extra (r >> 1) & 1 term keeps the 8 contiguous lanes
+// of a ds_write_b128 pass (4 rows x 2 k halves, banks mod 32) apart as well (without it: 2-way, SQ_LDS_BANK_CONFLICT = the write cycles again)
+__device__ __forceinline__ int sp_off(int r, int c) { return r * 64 + ((c ^ ((r >> 2) & 3) ^ ((r >> 1) & 1)) << 4); }
+
+__device__ __forceinline__ void split3(float v, __bf16 &h, __bf16 &m, __bf16 &l) {
+    h = (__bf16)v;
+    const float r1 = v - (float)h;
+    m = (__bf16)r1;
+    l = (__bf16)(r1 - (float)m);
+}
+
+__global__ void pw_split_weights_kernel(const float *__restrict__ w, int N, int K, int Kp, __bf16 *__restrict__ planes) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * K) return;
+    const int n = (int)(i / K), k = (int)(i - (long)n * K);
+    __bf16 h, m, l;
+    split3(w[(long)n * Kp + k], h, m, l);
+    const long plane = (long)N * K;
+    planes[i] = h; planes[plane + i] = m; planes[2 * plane + i] = l;
+}
+
+// VAR (probe only): 3 = fragments of a whole stage in registers, next stage's split + LDS writes between the MFMAs; 0 = loads one stage ahead; 1 = loads two stages ahead (two register sets); 2 = NO loads inside the loop (timing of
+// the LDS + MFMA structure alone; wrong results)
+template <bool RELU, bool RES, int VAR>
+__global__ __launch_bounds__(256, (VAR == 1 || VAR == 3) ? 2 : 3) void pw_split_kernel(const float *__restrict__ x, const __bf16 *__restrict__ wp, const float *__restrict__ bias,
+                                                           const float *__restrict__ res, float *__restrict__ y, int M, int N, int K) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * 3 * SP_PLANE * 2];
+    char *const la = lds;                                  // x planes
+    char *const lb = lds + 3 * SP_PLANE * 2;               // weight planes
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    // tile of this workgroup: n fastest (the n-tiles of a pixel block run side by side and share its rows in L2), and - workgroups being
+    // dealt round-robin to the 8 XCDs - consecutive tiles on ONE XCD when the count divides
+    const int nt_n = N / SP_BN, total = gridDim.x;
+    int lin = blockIdx.x;
+    if (total % 8 == 0) lin = (lin & 7) * (total >> 3) + (lin >> 3);
+    const int m0 = (lin / nt_n) * SP_BM, n0 = (lin % nt_n) * SP_BN;
+    // staging roles.  x: four rows (tid / 8 + 32 q), one 16-byte piece (4 k) of each - a wave-instruction reads 8 whole 128-byte row
+    // segments (two 16-byte pieces per row and instruction, the first form of this probe, cost four times the cache-line lookups);
+    // weights: row tid / 2 of each plane, 16 of the stage's 32 k
+    const int xrow = tid >> 3, xpc = tid & 7;
+    const float *xq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) xq[q] = x + (long)min(m0 + xrow + 32 * q, M - 1) * K + xpc * 4;
+    const int srow = tid >> 1, shalf = tid & 1;
+    const long wplane = (long)N * K;
+    const __bf16 *wg = wp + (long)(n0 + srow) * K + shalf * 16;
+
+    f32x4 xr[2][4];
+    bf16x8 wr[2][3][2];
+    auto load_stage = [&](int set, int k0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            xr[set][q] = *(const f32x4 *)(xq[q] + k0);      // rows beyond M: clamped to the last row (their outputs are never stored)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) wr[set][p][c] = *(const bf16x8 *)(wg + p * wplane + k0 + c * 8);
+    };
+    auto store_stage = [&](int set) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bf16x4 h, m, l;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                __bf16 a, b, d;
+                split3(xr[set][q][j], a, b, d);
+                h[j] = a; m[j] = b; l[j] = d;
+            }
+            const int o = sp_off(xrow + 32 * q, xpc >> 1) + (xpc & 1) * 8;
+            *(bf16x4 *)(la + o) = h;
+            *(bf16x4 *)(la + SP_PLANE * 2 + o) = m;
+            *(bf16x4 *)(la + 2 * SP_PLANE * 2 + o) = l;
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int o = sp_off(srow, shalf * 2 + c);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) *(bf16x8 *)(lb + p * SP_PLANE * 2 + o) = wr[set][p][c];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+    const int fr = lane & 31, fh = lane >> 5;
+    auto compute = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a[2][3], b[2][3];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int oa = sp_off(wm * 64 + i * 32 + fr, ks * 2 + fh), ob = sp_off(wn * 64 + i * 32 + fr, ks * 2 + fh);
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    a[i][p] = *(const bf16x8 *)(la + p * SP_PLANE * 2 + oa);
+                    b[i][p] = *(const bf16x8 *)(lb + p * SP_PLANE * 2 + ob);
+                }
+            }
+            // smallest terms first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    f32x16 c = acc[i][j];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);
+                    acc[i][j] = c;
+                }
+        }
+    };
+    if (VAR == 3) {
+        // the stage's fragments (24 ds_read_b128) go to registers in one burst; behind a second barrier the LDS buffer is free, and the
+        // split + LDS writes of the NEXT stage are issued between the MFMAs of the current one (sched_group_barrier pattern)
+        bf16x8 fa[2][2][3], fb[2][2][3];
+        auto read_frags = [&]() {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int oa = sp_off(wm * 64 + i * 32 + fr, ks * 2 + fh), ob = sp_off(wn * 64 + i * 32 + fr, ks * 2 + fh);
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        fa[ks][i][p] = *(const bf16x8 *)(la + p * SP_PLANE * 2 + oa);
+                        fb[ks][i][p] = *(const bf16x8 *)(lb + p * SP_PLANE * 2 + ob);
+                    }
+                }
+        };
+        auto mfmas = [&](int ks) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    f32x16 c = acc[i][j];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i][2], fb[ks][j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i][0], fb[ks][j][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i][1], fb[ks][j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i][1], fb[ks][j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i][0], fb[ks][j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i][0], fb[ks][j][0], c, 0, 0, 0);
+                    acc[i][j] = c;
+                }
+        };
+        auto pattern = [&]() {
+#pragma unroll
+            for (int i = 0; i < 24; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);       // five VALU (split arithmetic)
+                if (i % 4 != 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // 18 DS writes over 24 MFMAs
+            }
+        };
+        // global loads run TWO stages ahead in two register sets (one stage = ~1.5-4 k cycles; an L2 hit alone is > 1 k): stage s + 2 is
+        // requested at the top of stage s and split / written to LDS in the second half of stage s + 1
+        load_stage(0, 0);
+        store_stage(0);
+        if (SP_BK < K) load_stage(1, SP_BK);
+        __syncthreads();
+        for (int k0 = 0; k0 + SP_BK < K; k0 += 2 * SP_BK) {
+            if (k0 + 2 * SP_BK < K) load_stage(0, k0 + 2 * SP_BK);
+            __builtin_amdgcn_sched_barrier(0);            // (issued FIRST: left alone the scheduler sinks the loads towards their use)
+            read_frags();
+            __syncthreads();
+            mfmas(0);
+            __builtin_amdgcn_sched_barrier(0);            // keep the split out of the first half
+            mfmas(1);
+            store_stage(1);                               // interleaved with the 24 MFMAs above
+            pattern();
+            __syncthreads();
+            if (k0 + 2 * SP_BK < K) {
+                if (k0 + 3 * SP_BK < K) load_stage(1, k0 + 3 * SP_BK);
+                __builtin_amdgcn_sched_barrier(0);
+                read_frags();
+                __syncthreads();
+                mfmas(0);
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas(1);
+                store_stage(0);
+                pattern();
+                __syncthreads();
+            }
+        }
+        read_frags();
+        mfmas(0);
+        mfmas(1);
+    } else if (VAR == 1) {
+        load_stage(0, 0);
+        if (SP_BK < K) load_stage(1, SP_BK);
+        for (int k0 = 0; k0 < K; k0 += 2 * SP_BK) {
+            store_stage(0);
+            __syncthreads();
+            if (k0 + 2 * SP_BK < K) load_stage(0, k0 + 2 * SP_BK);
+            compute();
+            __syncthreads();
+            if (k0 + SP_BK < K) {
+                store_stage(1);
+                __syncthreads();
+                if (k0 + 3 * SP_BK < K) load_stage(1, k0 + 3 * SP_BK);
+                compute();
+                __syncthreads();
+            }
+        }
+    } else {
+        load_stage(0, 0);
+        for (int k0 = 0; k0 < K; k0 += SP_BK) {
+            store_stage(0);
+            __syncthreads();
+            if (VAR == 0 && k0 + SP_BK < K) load_stage(0, k0 + SP_BK);
+            compute();
+            __syncthreads();
+        }
+    }
+
+    // epilogue: register v of block (i, j): pixel row (v & 3) + 8 (v >> 2) + 4 (lane >> 5), channel lane & 31.  The 16 residual values of
+    // a block are requested together (rows clamped, not branched around), then added and stored
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + fr;
+        const float bz = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int mb = m0 + wm * 64 + i * 32 + 4 * fh;
+            float rv[16];
+            if (RES) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) rv[v] = res[(long)min(mb + (v & 3) + 8 * (v >> 2), M - 1) * N + n];
+            }
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int m = mb + (v & 3) + 8 * (v >> 2);
+                float o = acc[i][j][v] + bz;
+                if (RES) o += rv[v];
+                if (RELU) o = fmaxf(o, 0.f);
+                if (m < M) y[(long)m * N + n] = o;
+            }
+        }
+    }
+}
+
+// register-operand v_mfma_f32_32x32x16_bf16 loop (no memory traffic): the bf16 matrix rate the chip sustains, the yardstick of the probe
+__global__ __launch_bounds__(256) void bf16_rate_kernel(float *out, int iters, unsigned seed) {
+    bf16x8 a[2], b[2];
+    unsigned st = seed + threadIdx.x * 2654435761u + blockIdx.x * 40503u;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            st = st * 1664525u + 1013904223u; a[i][j] = (__bf16)(((st >> 8) & 0xffff) / 32768.f - 1.f);
+            st = st * 1664525u + 1013904223u; b[i][j] = (__bf16)((((st >> 8) & 0xffff) / 32768.f - 1.f) * 0.01f);
+        }
+    f32x16 c[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) c[q][v] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            c[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c[0], 0, 0, 0);
+            c[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c[1], 0, 0, 0);
+            c[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c[2], 0, 0, 0);
+            c[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c[3], 0, 0, 0);
+        }
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) sum += c[q][v];
+    out[(long)blockIdx.x * 256 + threadIdx.x] = sum;
+}
+
+// blocks of 4 waves; returns the FLOP of the launch
+double bf16_rate_launch(float *out, int blocks, int iters, hipStream_t s) {
+    hipLaunchKernelGGL(bf16_rate_kernel, dim3(blocks), dim3(256), 0, s, out, iters, 12345u);
+    return (double)blocks * 4 * iters * 16.0 * (2.0 * 32 * 32 * 16);
+}
+
+void pw_split_weights_launch(const float *w, int N, int K, int Kp, void *planes, hipStream_t s) {
+    const long n = (long)N * K;
+    hipLaunchKernelGGL(pw_split_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, N, K, Kp, (__bf16 *)planes);
+}
+
+template <int VAR>
+static void pw_split_launch_var(const float *x, const __bf16 *wp, const float *bias, const float *res, float *y, int M, int N, int K, int relu,
+                                hipStream_t s) {
+    const dim3 grid((unsigned)((M + SP_BM - 1) / SP_BM) * (unsigned)(N / SP_BN));
+    if (res) {
+        if (relu) hipLaunchKernelGGL((pw_split_kernel<true, true, VAR>), grid, dim3(256), 0, s, x, wp, bias, res, y, M, N, K);
+        else hipLaunchKernelGGL((pw_split_kernel<false, true, VAR>), grid, dim3(256), 0, s, x, wp, bias, res, y, M, N, K);
+    } else {
+        if (relu) hipLaunchKernelGGL((pw_split_kernel<true, false, VAR>), grid, dim3(256), 0, s, x, wp, bias, res, y, M, N, K);
+        else hipLaunchKernelGGL((pw_split_kernel<false, false, VAR>), grid, dim3(256), 0, s, x, wp, bias, res, y, M, N, K);
+    }
+}
+
+// M pixels x K channels -> N channels; K % 32 == 0 and N % 128 == 0 (the caller checks).  STCN_PW_SPLIT_VAR: probe variants (see the kernel)
+void pw_split_launch(const float *x, const void *planes, const float *bias, const float *res, float *y, int M, int N, int K, int relu,
+                     hipStream_t s) {
+    static const int var = getenv("STCN_PW_SPLIT_VAR") ? atoi(getenv("STCN_PW_SPLIT_VAR")) : 3;
+    const __bf16 *wp = (const __bf16 *)planes;
+    if (var == 0) pw_split_launch_var<0>(x, wp, bias, res, y, M, N, K, relu, s);
+    else if (var == 1) pw_split_launch_var<1>(x, wp, bias, res, y, M, N, K, relu, s);
+    else if (var == 2) pw_split_launch_var<2>(x, wp, bias, res, y, M, N, K, relu, s);
+    else pw_split_launch_var<3>(x, wp, bias, res, y, M, N, K, relu, s);
+}
+
+}  // namespace stcn

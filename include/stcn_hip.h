@@ -210,6 +210,16 @@ int stcn_bench_conv(void *stream, int B, int H, int W, int Cin, int Cout, int KH
  * matrix load is lower than the datasheet's). */
 int stcn_bench_mfma_rate(void *stream, int ms_target, float *tflops, float *ms_out);
 
+/* EXPERIMENT, not used by the engine (eva_vos_amd/csrc/pw_split.hip; tools/pw_split_probe.py): a pointwise convolution
+ * y[M][N] = x[M][K] . w[N][K]^T (+ bias[N], + res[M][N], ReLU) computed on the bf16 matrix pipe from a three-way split of the fp32
+ * operands (6 bf16 products per fp32 product, fp32 accumulation).  K % 32 == 0, N % 128 == 0.  One launch into y, then `iters`
+ * timed launches (HIP events on `stream`); avg_ms may be NULL when iters == 0. */
+int stcn_probe_pw_split(void *stream, const float *x, const float *wgt, const float *bias, const float *res, float *y,
+                        int M, int K, int N, int relu, int iters, float *avg_ms);
+
+/* EXPERIMENT: bf16 matrix rate (v_mfma_f32_32x32x16_bf16 on register operands, random data) with waves_per_simd waves on every SIMD. */
+int stcn_probe_bf16_rate(void *stream, int waves_per_simd, int iters, float *tflops);
+
 /* Per-kernel-class time of the last interact() measured with HIP events on the engine stream
  * (enabled by stcn_engine_set_profiling(e,1); adds a few % overhead).  ms[] indexed by STCN_K_*. */
 enum { STCN_K_CONV = 0, STCN_K_CONV_REDUCE, STCN_K_MEMREAD, STCN_K_ELEMWISE, STCN_K_CONV_N1,

@@ -1,0 +1,25 @@
+#!/bin/bash
+# GPU box: SQ counters of the split-bf16 pointwise probe on one shape (row 4 of tools/pw_split_probe.py: 512 -> 256 at M = 32400).
+# Counters in passes of their own, --kernel-trace only (no other trace domain).
+R=$(pwd); O=$R/gpurun_out/split; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
+ROW=${1:-4}
+for V in ${VARS:-1 2}; do
+  export STCN_PW_SPLIT_VAR=$V
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmcA$V -o p -- python3 $R/tools/pw_split_probe.py --only $ROW --iters 10 > $O/pmcA$V.log 2>&1
+  rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $O/pmcB$V -o p -- python3 $R/tools/pw_split_probe.py --only $ROW --iters 10 > $O/pmcB$V.log 2>&1
+  rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM --kernel-trace --output-format csv -d $O/pmcC$V -o p -- python3 $R/tools/pw_split_probe.py --only $ROW --iters 10 > $O/pmcC$V.log 2>&1
+  for P in A B C; do
+    f=$(find $O/pmc$P$V -name "p_counter_collection.csv" | head -1)
+    [ -n "$f" ] && python3 - "$f" "VAR=$V pass $P" <<'PY'
+import collections, csv, sys
+agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter(); seen = set()
+for r in csv.DictReader(open(sys.argv[1])):
+    k = r["Kernel_Name"].split("(")[0].replace("void ", "")[:60]
+    if "pw_split_kernel" not in k and "conv_gemm" not in k and "pw_chain" not in k: continue
+    agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+    if r["Dispatch_Id"] not in seen: seen.add(r["Dispatch_Id"]); n[k] += 1
+for k, c in agg.items():
+    print(sys.argv[2], k, "launches", n[k], " ".join(f"{a}={v / n[k]:.4g}" for a, v in sorted(c.items())))
+PY
+  done
+done

@@ -1,0 +1,76 @@
+"""GPU box: EXPERIMENT - the pointwise convs of the ResNet-50 key encoder on the bf16 matrix pipe from three-way
+split fp32 operands (eva_vos_amd/csrc/pw_split.hip, 6 bf16 products per fp32 product) against the product's exact-fp32 kernels:
+error of each against an fp64 reference on the same operands, and time per launch (HIP events, through the C ABI hooks).
+Usage: python tools/pw_split_probe.py [--iters 50] [--only ROW]"""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from gpu_util import call, dev, stream  # noqa: E402
+
+ITERS = int(sys.argv[sys.argv.index("--iters") + 1]) if "--iters" in sys.argv else 50
+ONLY = int(sys.argv[sys.argv.index("--only") + 1]) if "--only" in sys.argv else None           # one row of SHAPES (for counter runs)
+# (name, B, H, W, Cin, Cout, residual): the 1x1 convs with Cout % 128 == 0 of a 5-frame key-encoder group at 480x864, plus batch 1
+SHAPES = [
+    ("res2 conv3 64->256 +res", 5, 120, 216, 64, 256, 1),
+    ("layer2.0 conv1 256->128", 5, 120, 216, 256, 128, 0),
+    ("layer2 conv3 128->512 +res", 5, 60, 108, 128, 512, 1),
+    ("layer2 conv1 512->128", 5, 60, 108, 512, 128, 0),
+    ("layer3.0 conv1 512->256", 5, 60, 108, 512, 256, 0),
+    ("layer3 conv3 256->1024 +res", 5, 30, 54, 256, 1024, 1),
+    ("layer3 conv1 1024->256", 5, 30, 54, 1024, 256, 0),
+    ("layer3 conv3 256->1024 +res, one frame", 1, 30, 54, 256, 1024, 1),
+    ("res2 conv3 64->256 +res, one frame", 1, 120, 216, 64, 256, 1),
+]
+
+
+def main():
+    torch.set_grad_enabled(False)
+    print(f"{'layer':44s} {'M':>7s} {'fp32 us':>8s} {'split us':>8s} {'ratio':>6s} {'TF/s fp32':>9s} {'TF/s split':>10s}   max|err|/max|ref|: fp32   split   (rms: fp32   split)")
+    for wps in (1, 2, 4):
+        tf = C.c_float()
+        call("stcn_probe_bf16_rate", stream(), wps, 20000, C.byref(tf))
+        print(f"bf16 MFMA rate on register operands, {wps} wave(s) per SIMD: {tf.value:.0f} TFLOP/s = {tf.value / 6:.0f} TFLOP/s of fp32-equivalent products at 6 MFMAs each")
+    tot = [0.0, 0.0]
+    for name, B, H, W, Cin, Cout, use_res in (SHAPES if ONLY is None else SHAPES[ONLY:ONLY + 1]):
+        g = torch.Generator().manual_seed(Cin * 131 + Cout)
+        M = B * H * W
+        x = torch.relu(torch.randn(M, Cin, generator=g)) * torch.exp(torch.randn(M, 1, generator=g))   # post-ReLU activations, rows of unequal scale
+        w = torch.randn(Cout, Cin, generator=g) * (2.0 / Cin) ** 0.5
+        b = torch.randn(Cout, generator=g) * 0.1
+        res = torch.randn(M, Cout, generator=g) if use_res else None
+        xd, wd, bd = dev(x), dev(w), dev(b)
+        rd = dev(res) if use_res else None
+        ref = xd.double() @ wd.double().t() + bd.double()
+        if use_res:
+            ref = ref + rd.double()
+        ref = torch.relu(ref)
+        y32 = torch.empty(M, Cout, device="cuda")
+        call("stcn_test_conv", stream(), xd, wd, bd, rd, y32, B, H, W, Cin, Cout, 1, 1, 1, 0, 2, 0)
+        ysp = torch.empty(M, Cout, device="cuda")
+        ms_sp = C.c_float()
+        call("stcn_probe_pw_split", stream(), xd, wd, bd, rd, ysp, M, Cin, Cout, 1, ITERS, C.byref(ms_sp))
+        ms32, fl = C.c_float(), C.c_double()
+        if use_res:
+            os.environ["STCN_BENCH_CONV_RES"] = "1"
+        else:
+            os.environ.pop("STCN_BENCH_CONV_RES", None)
+        call("stcn_bench_conv", stream(), B, H, W, Cin, Cout, 1, 1, 1, 0, 0, ITERS, C.byref(ms32), C.byref(fl))
+        scale = ref.abs().max().item()
+        e32, esp = (y32.double() - ref).abs(), (ysp.double() - ref).abs()
+        tf = lambda ms: fl.value / (ms * 1e-3) / 1e12
+        tot[0] += ms32.value
+        tot[1] += ms_sp.value
+        print(f"{name:44s} {M:7d} {ms32.value * 1e3:8.1f} {ms_sp.value * 1e3:8.1f} {ms32.value / ms_sp.value:6.2f} {tf(ms32.value):9.1f} {tf(ms_sp.value):10.1f}"
+              f"   {e32.max().item() / scale:.2e} {esp.max().item() / scale:.2e}   ({e32.pow(2).mean().sqrt().item() / scale:.2e} {esp.pow(2).mean().sqrt().item() / scale:.2e})"
+              f"   split vs fp32 kernel: {(ysp - y32).abs().max().item() / scale:.2e}")
+    print(f"sum over the list: fp32 {tot[0] * 1e3:.1f} us, split {tot[1] * 1e3:.1f} us = {tot[0] / tot[1]:.2f}x")
+
+
+if __name__ == "__main__":
+    main()
