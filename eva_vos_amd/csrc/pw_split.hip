@@ -15,7 +15,9 @@
 // Workgroup: 256 threads = 4 waves as 2 (M) x 2 (N); tile 128 pixels x 128 output channels; each wave 2 x 2 blocks of 32 x 32.
 // K in stages of 32: the x tile is split on the fly while it is staged (the weights are split once, stcn::pw_split_weights_launch),
 // one LDS buffer [3 planes][128 rows][32 k] bf16 per operand (48 KB together: up to three workgroups per CU), the next stage's global
-// loads in flight under the current stage's MFMAs.
+// loads in flight under the current stage's MFMAs.  Variants (STCN_PW_SPLIT_VAR, default 3) and what each measured: DESIGN.md section 8,
+// profiles/r04_pw_split_probe.txt.  Finding: 1.0 - 1.4x the fp32 kernels on the key encoder's 1x1 convs; the limit is the operand feed (157 bf16
+// FLOP per L2 byte on this tile = 12 TB/s at the sustained bf16 rate), not the pipe.
 #include "kernels.h"
 
 namespace stcn {
@@ -277,6 +279,114 @@ __global__ __launch_bounds__(256, (VAR == 1 || VAR == 3) ? 2 : 3) void pw_split_
     }
 }
 
+// Variant 4: the same tile and LDS image with EIGHT waves (2 x 4, each 64 pixels x 32 channels = two blocks) and <= 128 registers: two
+// workgroups = four waves per SIMD, so that a SIMD has MFMA-phase waves beside staging-phase waves.  Plain order per stage (stage -> LDS,
+// barrier, next stage's global loads, two k-steps of 9 fragment reads + 12 MFMAs, barrier).
+template <bool RELU, bool RES>
+__global__ __launch_bounds__(512, 2) void pw_split8_kernel(const float *__restrict__ x, const __bf16 *__restrict__ wp, const float *__restrict__ bias,
+                                                            const float *__restrict__ res, float *__restrict__ y, int M, int N, int K) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * 3 * SP_PLANE * 2];
+    char *const la = lds;
+    char *const lb = lds + 3 * SP_PLANE * 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int nt_n = N / SP_BN, total = gridDim.x;
+    int lin = blockIdx.x;
+    if (total % 8 == 0) lin = (lin & 7) * (total >> 3) + (lin >> 3);
+    const int m0 = (lin / nt_n) * SP_BM, n0 = (lin % nt_n) * SP_BN;
+    const int xrow = tid >> 3, xpc = tid & 7;              // x: rows xrow, xrow + 64; one 16-byte piece of each
+    const float *xq[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) xq[q] = x + (long)min(m0 + xrow + 64 * q, M - 1) * K + xpc * 4;
+    const int srow = tid >> 2, sch = tid & 3;              // weights: row srow, 16-byte chunk sch of each plane
+    const long wplane = (long)N * K;
+    const __bf16 *wg = wp + (long)(n0 + srow) * K + sch * 8;
+
+    f32x4 xr[2];
+    bf16x8 wr[3];
+    auto load_stage = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) xr[q] = *(const f32x4 *)(xq[q] + k0);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) wr[p] = *(const bf16x8 *)(wg + p * wplane + k0);
+    };
+    auto store_stage = [&]() {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            bf16x4 h, m, l;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                __bf16 a, b, d;
+                split3(xr[q][j], a, b, d);
+                h[j] = a; m[j] = b; l[j] = d;
+            }
+            const int o = sp_off(xrow + 64 * q, xpc >> 1) + (xpc & 1) * 8;
+            *(bf16x4 *)(la + o) = h;
+            *(bf16x4 *)(la + SP_PLANE * 2 + o) = m;
+            *(bf16x4 *)(la + 2 * SP_PLANE * 2 + o) = l;
+        }
+        const int o = sp_off(srow, sch);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *(bf16x8 *)(lb + p * SP_PLANE * 2 + o) = wr[p];
+    };
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[i][v] = 0.f;
+    const int fr = lane & 31, fh = lane >> 5;
+    load_stage(0);
+    for (int k0 = 0; k0 < K; k0 += SP_BK) {
+        store_stage();
+        __syncthreads();
+        if (k0 + SP_BK < K) load_stage(k0 + SP_BK);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a[2][3], b[3];
+            const int ob = sp_off(wn * 32 + fr, ks * 2 + fh);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) b[p] = *(const bf16x8 *)(lb + p * SP_PLANE * 2 + ob);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int oa = sp_off(wm * 64 + i * 32 + fr, ks * 2 + fh);
+#pragma unroll
+                for (int p = 0; p < 3; ++p) a[i][p] = *(const bf16x8 *)(la + p * SP_PLANE * 2 + oa);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                f32x16 c = acc[i];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[0], c, 0, 0, 0);
+                acc[i] = c;
+            }
+        }
+        __syncthreads();
+    }
+    const int n = n0 + wn * 32 + fr;
+    const float bz = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int mb = m0 + wm * 64 + i * 32 + 4 * fh;
+        float rv[16];
+        if (RES) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) rv[v] = res[(long)min(mb + (v & 3) + 8 * (v >> 2), M - 1) * N + n];
+        }
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int m = mb + (v & 3) + 8 * (v >> 2);
+            float o = acc[i][v] + bz;
+            if (RES) o += rv[v];
+            if (RELU) o = fmaxf(o, 0.f);
+            if (m < M) y[(long)m * N + n] = o;
+        }
+    }
+}
+
 // register-operand v_mfma_f32_32x32x16_bf16 loop (no memory traffic): the bf16 matrix rate the chip sustains, the yardstick of the probe
 __global__ __launch_bounds__(256) void bf16_rate_kernel(float *out, int iters, unsigned seed) {
     bf16x8 a[2], b[2];
@@ -339,6 +449,17 @@ void pw_split_launch(const float *x, const void *planes, const float *bias, cons
                      hipStream_t s) {
     static const int var = getenv("STCN_PW_SPLIT_VAR") ? atoi(getenv("STCN_PW_SPLIT_VAR")) : 3;
     const __bf16 *wp = (const __bf16 *)planes;
+    if (var == 4) {
+        const dim3 grid((unsigned)((M + SP_BM - 1) / SP_BM) * (unsigned)(N / SP_BN));
+        if (res) {
+            if (relu) hipLaunchKernelGGL((pw_split8_kernel<true, true>), grid, dim3(512), 0, s, x, wp, bias, res, y, M, N, K);
+            else hipLaunchKernelGGL((pw_split8_kernel<false, true>), grid, dim3(512), 0, s, x, wp, bias, res, y, M, N, K);
+        } else {
+            if (relu) hipLaunchKernelGGL((pw_split8_kernel<true, false>), grid, dim3(512), 0, s, x, wp, bias, res, y, M, N, K);
+            else hipLaunchKernelGGL((pw_split8_kernel<false, false>), grid, dim3(512), 0, s, x, wp, bias, res, y, M, N, K);
+        }
+        return;
+    }
     if (var == 0) pw_split_launch_var<0>(x, wp, bias, res, y, M, N, K, relu, s);
     else if (var == 1) pw_split_launch_var<1>(x, wp, bias, res, y, M, N, K, relu, s);
     else if (var == 2) pw_split_launch_var<2>(x, wp, bias, res, y, M, N, K, relu, s);

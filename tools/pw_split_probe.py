@@ -29,6 +29,10 @@ SHAPES = [
 ]
 
 
+if "--ksweep" in sys.argv:            # fixed M = 32400 pixels, N = 256: time against K separates the per-stage cost from the fixed part of a launch
+    SHAPES = [(f"K sweep {k}->256", 5, 60, 108, k, 256, 0) for k in (32, 64, 128, 256, 512, 1024, 2048)]
+
+
 def main():
     torch.set_grad_enabled(False)
     print(f"{'layer':44s} {'M':>7s} {'fp32 us':>8s} {'split us':>8s} {'ratio':>6s} {'TF/s fp32':>9s} {'TF/s split':>10s}   max|err|/max|ref|: fp32   split   (rms: fp32   split)")
