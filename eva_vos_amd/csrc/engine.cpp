@@ -148,6 +148,9 @@ int make_wino4(Model &m, ConvW &cw, const std::vector<float> &w) {
 static bool decoder_layer(const std::string &name) {
     // round 4: also the value encoder's ResNet-18 trunk (its 128- and 256-channel stride-1 3x3 convs): everything in the value encoder
     // ends in memory VALUES; at batch 1 these layers are small launches, which F(4x4) now covers by cutting every tile into K pieces
+    // STCN_WINO4_KEY=1 (experiment, off): also the key encoder's trunk and key_proj (measured, parity A/B)
+    static const bool key4 = [] { const char *e = getenv("STCN_WINO4_KEY"); return e && atoi(e) != 0; }();
+    if (key4 && (name.compare(0, 12, "key_encoder.") == 0 || name == "key_proj")) return true;
     return name.compare(0, 8, "decoder.") == 0 || name == "key_comp" || name.compare(0, 20, "value_encoder.fuser.") == 0 ||
            name.compare(0, 19, "value_encoder.layer") == 0;
 }

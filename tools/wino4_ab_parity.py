@@ -48,7 +48,10 @@ def main():
     torch.set_grad_enabled(False)
     tmp = tempfile.mkdtemp()
     arms = {}
-    for name, env in (("wino4", {}), ("no_wino4", {"STCN_WINO4": "0"})):
+    arms_list = [("wino4", {}), ("no_wino4", {"STCN_WINO4": "0"})]
+    if "--key" in sys.argv:                      # third arm: F(4x4) also in the key encoder's trunk + key_proj (STCN_WINO4_KEY=1, experiment)
+        arms_list.append(("wino4_key", {"STCN_WINO4_KEY": "1"}))
+    for name, env in arms_list:
         out = os.path.join(tmp, name + ".npz")
         subprocess.check_call([sys.executable, os.path.abspath(__file__), "--frames", str(T), "--child", out], env=dict(os.environ, **env))
         arms[name] = np.load(out)
@@ -69,7 +72,10 @@ def main():
             fiou = np.where(fu >= 64, fi / np.maximum(fu, 1), 1.0)
             row.append(f"{name}: {int((a != b).sum())} px differ from the CPU oracle (clip IoU {(a & b).sum() / max((a | b).sum(), 1):.6f}, worst frame {fiou.min():.6f} @ {int(fiou.argmin())})")
         ab = int(((arms['wino4'][tag] > 0) != (arms['no_wino4'][tag] > 0)).sum())
-        print(f"{tag} ({tot} px): " + "; ".join(row) + f"; the two arms differ from each other on {ab} px", flush=True)
+        extra = ""
+        if "wino4_key" in arms:
+            extra = f"; wino4_key differs from wino4 on {int(((arms['wino4_key'][tag] > 0) != (arms['wino4'][tag] > 0)).sum())} px"
+        print(f"{tag} ({tot} px): " + "; ".join(row) + f"; the two arms differ from each other on {ab} px" + extra, flush=True)
 
 
 if __name__ == "__main__":
