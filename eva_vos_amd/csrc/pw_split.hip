@@ -64,10 +64,11 @@ __global__ __launch_bounds__(256, (VAR == 1 || VAR == 3) ? 2 : 3) void pw_split_
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     // tile of this workgroup: n fastest (the n-tiles of a pixel block run side by side and share its rows in L2), and - workgroups being
-    // dealt round-robin to the 8 XCDs - consecutive tiles on ONE XCD when the count divides
-    const int nt_n = N / SP_BN, total = gridDim.x;
-    int lin = blockIdx.x;
-    if (total % 8 == 0) lin = (lin & 7) * (total >> 3) + (lin >> 3);
+    // dealt round-robin to the 8 XCDs - consecutive tiles on ONE XCD (without this the sibling n-tiles sit on different XCDs and the
+    // activations come out of HBM / MALL once per n-tile: TCC_MISS 2.5x the compulsory lines)
+    const int nt_n = N / SP_BN;
+    const int lin = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);      // the grid is padded to a multiple of 8 (launch)
+    if (lin >= nt_n * ((M + SP_BM - 1) / SP_BM)) return;
     const int m0 = (lin / nt_n) * SP_BM, n0 = (lin % nt_n) * SP_BN;
     // staging roles.  x: four rows (tid / 8 + 32 q), one 16-byte piece (4 k) of each - a wave-instruction reads 8 whole 128-byte row
     // segments (two 16-byte pieces per row and instruction, the first form of this probe, cost four times the cache-line lookups);
@@ -290,9 +291,9 @@ __global__ __launch_bounds__(512, 2) void pw_split8_kernel(const float *__restri
     char *const lb = lds + 3 * SP_PLANE * 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
-    const int nt_n = N / SP_BN, total = gridDim.x;
-    int lin = blockIdx.x;
-    if (total % 8 == 0) lin = (lin & 7) * (total >> 3) + (lin >> 3);
+    const int nt_n = N / SP_BN;
+    const int lin = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);      // the grid is padded to a multiple of 8 (launch)
+    if (lin >= nt_n * ((M + SP_BM - 1) / SP_BM)) return;
     const int m0 = (lin / nt_n) * SP_BM, n0 = (lin % nt_n) * SP_BN;
     const int xrow = tid >> 3, xpc = tid & 7;              // x: rows xrow, xrow + 64; one 16-byte piece of each
     const float *xq[2];
@@ -434,7 +435,7 @@ void pw_split_weights_launch(const float *w, int N, int K, int Kp, void *planes,
 template <int VAR>
 static void pw_split_launch_var(const float *x, const __bf16 *wp, const float *bias, const float *res, float *y, int M, int N, int K, int relu,
                                 hipStream_t s) {
-    const dim3 grid((unsigned)((M + SP_BM - 1) / SP_BM) * (unsigned)(N / SP_BN));
+    const dim3 grid((((unsigned)((M + SP_BM - 1) / SP_BM) * (unsigned)(N / SP_BN)) + 7u) / 8u * 8u);
     if (res) {
         if (relu) hipLaunchKernelGGL((pw_split_kernel<true, true, VAR>), grid, dim3(256), 0, s, x, wp, bias, res, y, M, N, K);
         else hipLaunchKernelGGL((pw_split_kernel<false, true, VAR>), grid, dim3(256), 0, s, x, wp, bias, res, y, M, N, K);
@@ -450,7 +451,7 @@ void pw_split_launch(const float *x, const void *planes, const float *bias, cons
     static const int var = getenv("STCN_PW_SPLIT_VAR") ? atoi(getenv("STCN_PW_SPLIT_VAR")) : 3;
     const __bf16 *wp = (const __bf16 *)planes;
     if (var == 4) {
-        const dim3 grid((unsigned)((M + SP_BM - 1) / SP_BM) * (unsigned)(N / SP_BN));
+        const dim3 grid((((unsigned)((M + SP_BM - 1) / SP_BM) * (unsigned)(N / SP_BN)) + 7u) / 8u * 8u);
         if (res) {
             if (relu) hipLaunchKernelGGL((pw_split8_kernel<true, true>), grid, dim3(512), 0, s, x, wp, bias, res, y, M, N, K);
             else hipLaunchKernelGGL((pw_split8_kernel<false, true>), grid, dim3(512), 0, s, x, wp, bias, res, y, M, N, K);

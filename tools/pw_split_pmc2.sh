@@ -1,0 +1,26 @@
+#!/bin/bash
+# GPU box: memory-path counters of the split-bf16 probe (variant $VARS, row $1 of tools/pw_split_probe.py) next to the fp32 pointwise kernel of the same run.
+R=$(pwd); O=$R/gpurun_out/split; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
+ROW=${1:-4}
+for V in ${VARS:-4}; do
+  export STCN_PW_SPLIT_VAR=$V
+  i=0
+  for C in "TA_BUSY_avr TA_TA_BUSY_sum GRBM_GUI_ACTIVE" "TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "FETCH_SIZE" "SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_INST_CYCLES_VMEM"; do
+    i=$((i+1))
+    rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/m$V$i -o p -- python3 $R/tools/pw_split_probe.py --only $ROW --iters 10 > $O/m$V$i.log 2>&1
+    f=$(find $O/m$V$i -name "p_counter_collection.csv" | head -1)
+    if [ -n "$f" ]; then python3 - "$f" "VAR=$V" <<'PY'
+import collections, csv, sys
+agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter(); seen = set(); dur = collections.defaultdict(float)
+for r in csv.DictReader(open(sys.argv[1])):
+    k = r["Kernel_Name"].split("(")[0].replace("void ", "")[:48]
+    if "pw_split" not in k and "pw_chain" not in k and "conv_gemm" not in k: continue
+    agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+    if r["Dispatch_Id"] not in seen:
+        seen.add(r["Dispatch_Id"]); n[k] += 1; dur[k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+for k, c in agg.items():
+    print(sys.argv[2], k, f"launches {n[k]} avg {dur[k] / n[k]:.1f} us", " ".join(f"{a}={v / n[k]:.4g}" for a, v in sorted(c.items())))
+PY
+    else echo "pass $i [$C]: no counters ($(grep -i -m1 "error\|invalid\|not found" $O/m$V$i.log | cut -c1-160))"; fi
+  done
+done
