@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256, (VAR == 1 || VAR == 3) ? 2 : 3) void pw_split_
 // barrier, next stage's global loads, two k-steps of 9 fragment reads + 12 MFMAs, barrier).
 template <bool RELU, bool RES>
 __global__ __launch_bounds__(512, 2) void pw_split8_kernel(const float *__restrict__ x, const __bf16 *__restrict__ wp, const float *__restrict__ bias,
-                                                            const float *__restrict__ res, float *__restrict__ y, int M, int N, int K) {
+                                                            const float *__restrict__ res, float *__restrict__ y, int M, int N, int K, int skip) {
     __shared__ __attribute__((aligned(16))) char lds[2 * 3 * SP_PLANE * 2];
     char *const la = lds;
     char *const lb = lds + 3 * SP_PLANE * 2;
@@ -305,11 +305,16 @@ __global__ __launch_bounds__(512, 2) void pw_split8_kernel(const float *__restri
 
     f32x4 xr[2];
     bf16x8 wr[3];
+    // skip (probe only, wrong results): bit 0 = no activation loads inside the loop, bit 1 = no weight loads inside the loop
     auto load_stage = [&](int k0) {
+        if (k0 == 0 || !(skip & 1)) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) xr[q] = *(const f32x4 *)(xq[q] + k0);
+            for (int q = 0; q < 2; ++q) xr[q] = *(const f32x4 *)(xq[q] + k0);
+        }
+        if (k0 == 0 || !(skip & 2)) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) wr[p] = *(const bf16x8 *)(wg + p * wplane + k0);
+            for (int p = 0; p < 3; ++p) wr[p] = *(const bf16x8 *)(wg + p * wplane + k0);
+        }
     };
     auto store_stage = [&]() {
 #pragma unroll
@@ -388,6 +393,155 @@ __global__ __launch_bounds__(512, 2) void pw_split8_kernel(const float *__restri
     }
 }
 
+// Variant 5: producer / consumer waves.  Eight waves: 0-3 consume (2 x 2 waves of 64 x 64, MFMAs + fragment reads only - they never issue a
+// global load), 4-7 produce (global loads two stages ahead in two register sets, split, LDS writes).  Two LDS buffers of 48 KB (dynamic
+// shared memory, one workgroup per CU), ONE barrier per stage: in iteration s the producers fill buffer s & 1 with stage s while the
+// consumers work on stage s - 1 out of the other one.
+template <bool RELU, bool RES>
+__global__ __launch_bounds__(512, 1) void pw_split_ws_kernel(const float *__restrict__ x, const __bf16 *__restrict__ wp, const float *__restrict__ bias,
+                                                              const float *__restrict__ res, float *__restrict__ y, int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) char lds_dyn[];
+    constexpr int BUF = 2 * 3 * SP_PLANE * 2;              // bytes of one buffer: x planes, then weight planes
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nt_n = N / SP_BN;
+    const int lin = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    if (lin >= nt_n * ((M + SP_BM - 1) / SP_BM)) return;
+    const int m0 = (lin / nt_n) * SP_BM, n0 = (lin % nt_n) * SP_BN;
+    const int S = K / SP_BK;
+    if (wave >= 4) {
+        // ---------------- producers
+        const int lt = tid - 256;
+        const int xrow = lt >> 3, xpc = lt & 7;
+        const float *xq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xq[q] = x + (long)min(m0 + xrow + 32 * q, M - 1) * K + xpc * 4;
+        const int srow = lt >> 1, shalf = lt & 1;
+        const long wplane = (long)N * K;
+        const __bf16 *wg = wp + (long)(n0 + srow) * K + shalf * 16;
+        f32x4 xr[2][4];
+        bf16x8 wr[2][3][2];
+        auto load_stage = [&](int set, int k0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xr[set][q] = *(const f32x4 *)(xq[q] + k0);
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) wr[set][p][c] = *(const bf16x8 *)(wg + p * wplane + k0 + c * 8);
+        };
+        auto store_stage = [&](int set, char *la) {
+            char *lb = la + 3 * SP_PLANE * 2;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                bf16x4 h, m, l;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    __bf16 a, b, d;
+                    split3(xr[set][q][j], a, b, d);
+                    h[j] = a; m[j] = b; l[j] = d;
+                }
+                const int o = sp_off(xrow + 32 * q, xpc >> 1) + (xpc & 1) * 8;
+                *(bf16x4 *)(la + o) = h;
+                *(bf16x4 *)(la + SP_PLANE * 2 + o) = m;
+                *(bf16x4 *)(la + 2 * SP_PLANE * 2 + o) = l;
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int o = sp_off(srow, shalf * 2 + c);
+#pragma unroll
+                for (int p = 0; p < 3; ++p) *(bf16x8 *)(lb + p * SP_PLANE * 2 + o) = wr[set][p][c];
+            }
+        };
+        load_stage(0, 0);
+        if (S > 1) load_stage(1, SP_BK);
+        for (int s = 0; s < S; s += 2) {
+            store_stage(0, lds_dyn);
+            if (s + 2 < S) load_stage(0, (s + 2) * SP_BK);
+            __syncthreads();
+            if (s + 1 < S) {
+                store_stage(1, lds_dyn + BUF);
+                if (s + 3 < S) load_stage(1, (s + 3) * SP_BK);
+                __syncthreads();
+            }
+        }
+        return;
+    }
+    // ---------------- consumers
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 31, fh = lane >> 5;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+    auto compute = [&](const char *la) {
+        const char *lb = la + 3 * SP_PLANE * 2;
+        bf16x8 a[2][2][3], b[2][2][3];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int oa = sp_off(wm * 64 + i * 32 + fr, ks * 2 + fh), ob = sp_off(wn * 64 + i * 32 + fr, ks * 2 + fh);
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    a[ks][i][p] = *(const bf16x8 *)(la + p * SP_PLANE * 2 + oa);
+                    b[ks][i][p] = *(const bf16x8 *)(lb + p * SP_PLANE * 2 + ob);
+                }
+            }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    f32x16 c = acc[i][j];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][i][2], b[ks][j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][i][0], b[ks][j][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][i][1], b[ks][j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][i][1], b[ks][j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][i][0], b[ks][j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][i][0], b[ks][j][0], c, 0, 0, 0);
+                    acc[i][j] = c;
+                }
+    };
+    for (int s = 0; s < S; ++s) {
+        if (s > 0) compute(lds_dyn + ((s - 1) & 1) * BUF);
+        __syncthreads();
+    }
+    compute(lds_dyn + ((S - 1) & 1) * BUF);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + fr;
+        const float bz = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int mb = m0 + wm * 64 + i * 32 + 4 * fh;
+            float rv[16];
+            if (RES) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) rv[v] = res[(long)min(mb + (v & 3) + 8 * (v >> 2), M - 1) * N + n];
+            }
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int m = mb + (v & 3) + 8 * (v >> 2);
+                float o = acc[i][j][v] + bz;
+                if (RES) o += rv[v];
+                if (RELU) o = fmaxf(o, 0.f);
+                if (m < M) y[(long)m * N + n] = o;
+            }
+        }
+    }
+}
+
+template <bool RELU, bool RES>
+static void pw_split_ws_go(dim3 grid, hipStream_t s, const float *x, const __bf16 *wp, const float *bias, const float *res, float *y, int M, int N, int K) {
+    constexpr int bytes = 2 * 2 * 3 * SP_PLANE * 2;
+    static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(&pw_split_ws_kernel<RELU, RES>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    (void)once;
+    hipLaunchKernelGGL((pw_split_ws_kernel<RELU, RES>), grid, dim3(512), bytes, s, x, wp, bias, res, y, M, N, K);
+}
+
 // register-operand v_mfma_f32_32x32x16_bf16 loop (no memory traffic): the bf16 matrix rate the chip sustains, the yardstick of the probe
 __global__ __launch_bounds__(256) void bf16_rate_kernel(float *out, int iters, unsigned seed) {
     bf16x8 a[2], b[2];
@@ -450,14 +604,21 @@ void pw_split_launch(const float *x, const void *planes, const float *bias, cons
                      hipStream_t s) {
     static const int var = getenv("STCN_PW_SPLIT_VAR") ? atoi(getenv("STCN_PW_SPLIT_VAR")) : 3;
     const __bf16 *wp = (const __bf16 *)planes;
+    if (var == 5) {
+        const dim3 grid((((unsigned)((M + SP_BM - 1) / SP_BM) * (unsigned)(N / SP_BN)) + 7u) / 8u * 8u);
+        if (res) { if (relu) pw_split_ws_go<true, true>(grid, s, x, wp, bias, res, y, M, N, K); else pw_split_ws_go<false, true>(grid, s, x, wp, bias, res, y, M, N, K); }
+        else { if (relu) pw_split_ws_go<true, false>(grid, s, x, wp, bias, res, y, M, N, K); else pw_split_ws_go<false, false>(grid, s, x, wp, bias, res, y, M, N, K); }
+        return;
+    }
     if (var == 4) {
         const dim3 grid((((unsigned)((M + SP_BM - 1) / SP_BM) * (unsigned)(N / SP_BN)) + 7u) / 8u * 8u);
+        static const int skip = getenv("STCN_PW_SPLIT_SKIP") ? atoi(getenv("STCN_PW_SPLIT_SKIP")) : 0;
         if (res) {
-            if (relu) hipLaunchKernelGGL((pw_split8_kernel<true, true>), grid, dim3(512), 0, s, x, wp, bias, res, y, M, N, K);
-            else hipLaunchKernelGGL((pw_split8_kernel<false, true>), grid, dim3(512), 0, s, x, wp, bias, res, y, M, N, K);
+            if (relu) hipLaunchKernelGGL((pw_split8_kernel<true, true>), grid, dim3(512), 0, s, x, wp, bias, res, y, M, N, K, skip);
+            else hipLaunchKernelGGL((pw_split8_kernel<false, true>), grid, dim3(512), 0, s, x, wp, bias, res, y, M, N, K, skip);
         } else {
-            if (relu) hipLaunchKernelGGL((pw_split8_kernel<true, false>), grid, dim3(512), 0, s, x, wp, bias, res, y, M, N, K);
-            else hipLaunchKernelGGL((pw_split8_kernel<false, false>), grid, dim3(512), 0, s, x, wp, bias, res, y, M, N, K);
+            if (relu) hipLaunchKernelGGL((pw_split8_kernel<true, false>), grid, dim3(512), 0, s, x, wp, bias, res, y, M, N, K, skip);
+            else hipLaunchKernelGGL((pw_split8_kernel<false, false>), grid, dim3(512), 0, s, x, wp, bias, res, y, M, N, K, skip);
         }
         return;
     }
