@@ -15,7 +15,7 @@
 // Workgroup: 256 threads = 4 waves as 2 (M) x 2 (N); tile 128 pixels x 128 output channels; each wave 2 x 2 blocks of 32 x 32.
 // K in stages of 32: the x tile is split on the fly while it is staged (the weights are split once, stcn::pw_split_weights_launch),
 // one LDS buffer [3 planes][128 rows][32 k] bf16 per operand (48 KB together: up to three workgroups per CU), the next stage's global
-// loads in flight under the current stage's MFMAs.  Variants (STCN_PW_SPLIT_VAR, default 3) and what each measured: DESIGN.md section 8,
+// loads in flight under the current stage's MFMAs.  Variants (STCN_PW_SPLIT_VAR, default 4 = the 8-wave form) and what each measured: DESIGN.md section 8,
 // profiles/r04_pw_split_probe.txt.  Finding: 1.0 - 1.4x the fp32 kernels on the key encoder's 1x1 convs; the limit is the operand feed (157 bf16
 // FLOP per L2 byte on this tile = 12 TB/s at the sustained bf16 rate), not the pipe.
 #include "kernels.h"
@@ -602,7 +602,7 @@ static void pw_split_launch_var(const float *x, const __bf16 *wp, const float *b
 // M pixels x K channels -> N channels; K % 32 == 0 and N % 128 == 0 (the caller checks).  STCN_PW_SPLIT_VAR: probe variants (see the kernel)
 void pw_split_launch(const float *x, const void *planes, const float *bias, const float *res, float *y, int M, int N, int K, int relu,
                      hipStream_t s) {
-    static const int var = getenv("STCN_PW_SPLIT_VAR") ? atoi(getenv("STCN_PW_SPLIT_VAR")) : 3;
+    static const int var = getenv("STCN_PW_SPLIT_VAR") ? atoi(getenv("STCN_PW_SPLIT_VAR")) : 4;
     const __bf16 *wp = (const __bf16 *)planes;
     if (var == 5) {
         const dim3 grid((((unsigned)((M + SP_BM - 1) / SP_BM) * (unsigned)(N / SP_BN)) + 7u) / 8u * 8u);
