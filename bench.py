@@ -53,15 +53,19 @@ def ref_self_noise(*tags):
     return np.max(np.concatenate([d[t] for t in tags], 0), 0)
 
 
-def clip_bound(noise):
-    """Per-object mask bound on a whole clip (1 - IoU): the north_star 1e-3, or 3 x the reference's own spread on the nearest fixture."""
-    return max(1e-3, 3.0 * float(noise[0]))
+NOISE_X = 1.5      # allowance over the reference's own per-frame spread (round 6: 1.5, was 3 - see tests/conftest.py)
+
+
+def clip_bound(noise=None):
+    """Per-object mask bound on a whole clip (1 - IoU): the north_star's plain 1e-3, for every k (round 6: every leg of this bench measures
+    <= 2.9e-4 at 480p; the reference's own clip-level spread there is <= 6e-4, so no allowance over it is needed)."""
+    return 1e-3
 
 
 def frame_bound(noise, union_px):
-    """Per-(object, frame) mask bound (1 - IoU), the form of tests/conftest.py::frame_bound: the north_star 1e-3, or 3 x the reference's own
+    """Per-(object, frame) mask bound (1 - IoU), the form of tests/conftest.py::frame_bound: the north_star 1e-3, or 1.5 x the reference's own
     worst per-frame difference between its thread counts, or - small objects - two pixels, whichever is larger."""
-    return max(1e-3, 3.0 * float(noise[4]), 2.0 / max(float(union_px), 1.0))
+    return max(1e-3, NOISE_X * float(noise[4]), 2.0 / max(float(union_px), 1.0))
 
 
 def parse():
@@ -108,6 +112,9 @@ def parse():
                     help="skip the `drivers` leg (eval_driver + fq_driver rounds/s on a synthetic 480p dataset tree: configs 4 / 5 at N = 1)")
     ap.add_argument("--driver-videos", type=int, default=8)
     ap.add_argument("--driver-frames", type=int, default=40)
+    ap.add_argument("--no-session", dest="session", action="store_false",
+                    help="skip the `session` leg (configs 4 / 5 as resident-clip annotation sessions: 8 and 60 oracle rounds, lane sweep)")
+    ap.add_argument("--session-videos", type=int, default=4)
     ap.add_argument("--no-r2", dest="r2", action="store_false",
                     help="skip the extra R2 number (a second interaction: cached keys + fusion; reported, not the headline)")
     return ap.parse_args()
@@ -186,6 +193,7 @@ def parity_vs_oracle(prop, fuse, sample, mem_freq, eo=None):
         noise = ref_self_noise("seq480", "seq480L", "seq480P")
         fb = np.array([frame_bound(noise, u) for u in fu])
         out[f"within_bound_{tag}"] = bool(1 - out[f"mask_iou_hip_vs_cpu_oracle_{tag}"] <= clip_bound(noise) and (1 - fiou <= fb).all())
+        out[f"measured_over_bound_{tag}"] = {"clip": (1 - out[f"mask_iou_hip_vs_cpu_oracle_{tag}"]) / clip_bound(noise), "worst_frame": float(((1 - fiou) / fb).max())}
     out["mask_pixels_total"] = int(got1.size)
     # interacted frames carry no propagated mask (the callers overwrite them): score the others
     keep = np.ones(img.shape[1], bool)
@@ -379,6 +387,7 @@ def config3_parity(prop, fuse, psd, fsd, T, H, W, k):
         wf = int(np.argmax((1 - fiou) / fb))                           # the frame closest to (or furthest beyond) ITS bound
         row = dict(object=o, clip_miss=1 - ious[-1], clip_bound=clip_bound(noise), worst_frame=wf, worst_frame_miss=float(1 - fiou[wf]),
                    worst_frame_bound=float(fb[wf]), worst_frame_union_px=int(fu[wf]),
+                   measured_over_bound={"clip": (1 - ious[-1]) / clip_bound(noise), "worst_frame": float(((1 - fiou) / fb).max())},
                    within_bound=bool(1 - ious[-1] <= clip_bound(noise) and (1 - fiou <= fb).all()))
         per_obj.append(row)
         ok = ok and row["within_bound"]
@@ -386,7 +395,7 @@ def config3_parity(prop, fuse, psd, fsd, T, H, W, k):
             fmin, fwhere = float(fiou.min()), (o, int(fiou.argmin()))
     out.update(mask_iou_vs_cpu_oracle_per_object=ious, mask_iou_vs_cpu_oracle=min(ious), min_frame_iou=fmin, min_frame_iou_object_frame=fwhere,
                per_object=per_obj, within_bound=ok,
-               bound="clip: max(1e-3, 3 x reference self-noise); (object, frame): max(1e-3, 3 x reference per-frame self-noise, 2 px / union px) - "
+               bound="clip: 1e-3 flat; (object, frame): max(1e-3, 1.5 x reference per-frame self-noise, 2 px / union px) - "
                      f"self-noise = tests/golden/selfnoise.npz rows {' / '.join(tags)} (the reference against itself at different thread counts)",
                reference_self_noise=dict(clip_miss=float(noise[0]), frame_miss=float(noise[4]), differing_px=float(noise[3])),
                what="mask_iou_vs_cpu_oracle = worst object over ALL pixels of the clip; min_frame_iou = worst (object, frame); within_bound = every object on the clip AND on every frame")
@@ -420,7 +429,8 @@ def long_clip_parity(prop, fuse, psd, fsd, H, W, T, mem_freq, eo=None):
                 mask_pixels_total=int(got.size), min_frame_iou=float(fiou.min()), min_frame_iou_frame=int(fiou.argmin()),
                 min_frame_iou_by_quarter_of_the_clip=quarters, clip_bound=clip_bound(noise), frame_bound=float(fb[int(fiou.argmin())]),
                 within_bound=bool(1 - float((a_ & b_).sum() / max((a_ | b_).sum(), 1)) <= clip_bound(noise) and (1 - fiou <= fb).all()),
-                bound="clip: max(1e-3, 3 x reference self-noise); every frame: max(1e-3, 3 x reference per-frame self-noise, 2 px / union px)")
+                measured_over_bound={"clip": (1 - float((a_ & b_).sum() / max((a_ | b_).sum(), 1))) / clip_bound(noise), "worst_frame": float(((1 - fiou) / fb).max())},
+                bound="clip: 1e-3 flat; every frame: max(1e-3, 1.5 x reference per-frame self-noise, 2 px / union px)")
 
 
 def session_parity(prop, fuse, psd, fsd, H, W, T, rounds, mem_freq, eo=None):
@@ -464,6 +474,7 @@ def session_parity(prop, fuse, psd, fsd, H, W, T, rounds, mem_freq, eo=None):
                          min_frame_iou=float(fiou.min()), min_frame_iou_frame=int(fiou.argmin()), mean_j_oracle=float(q_ref.mean()), mean_j_hip=float(q_got.mean()),
                          next_frame_oracle=nxt, next_frame_hip=int(np.argmin(q_got)),
                          clip_bound=clip_bound(noise), frame_bound=float(fb[int(fiou.argmin())]),
+                         measured_over_bound={"clip": (1 - miou) / clip_bound(noise), "worst_frame": float(((1 - fiou) / fb).max())},
                          within_bound=bool(1 - miou <= clip_bound(noise) and (1 - fiou <= fb).all())))
         frames.append(nxt)
     st = core.stats()
@@ -474,8 +485,9 @@ def session_parity(prop, fuse, psd, fsd, H, W, T, rounds, mem_freq, eo=None):
                 worst_round_mask_iou=min(r_["mask_iou"] for r_ in rows), worst_round_min_frame_iou=min(r_["min_frame_iou"] for r_ in rows),
                 same_frame_choice_every_round=all(r_["next_frame_oracle"] == r_["next_frame_hip"] for r_ in rows),
                 within_bound=all(r_["within_bound"] for r_ in rows),
+                worst_measured_over_bound={"clip": max(r_["measured_over_bound"]["clip"] for r_ in rows), "worst_frame": max(r_["measured_over_bound"]["worst_frame"] for r_ in rows)},
                 last_round_stats=st, rounds=rows,
-                bound="per round - clip: max(1e-3, 3 x reference self-noise); every frame: max(1e-3, 3 x reference per-frame self-noise, 2 px / union px); "
+                bound="per round - clip: 1e-3 flat; every frame: max(1e-3, 1.5 x reference per-frame self-noise, 2 px / union px); "
                       "self-noise = tests/golden/selfnoise.npz rows seq480 / seq480L / seq480P")
 
 
@@ -629,21 +641,110 @@ def drivers_leg(prop, fuse, H, W, videos, frames, lanes=2, rounds=8):
         out = {"dataset": f"{videos} synthetic single-object videos x {frames} frames ({videos - 1} x {H}x{W} + 1 portrait {W}x{H}) in the DAVIS layout "
                           f"(JPEG frames, palette PNG annotations; written in {t_tree:.1f} s, outside the timed regions)",
                "lanes": lanes, "rounds_per_sample": rounds}
-        for name, fn in (("fq_driver", lambda: fq_driver.run(os.path.join(tmp, "db"), imset, os.path.join(tmp, "fq"), prop, fuse, rounds=rounds, lanes=lanes)),
-                         ("eval_driver_oracle_mask", lambda: eval_driver.run(os.path.join(tmp, "db"), imset, os.path.join(tmp, "e.csv"), prop, fuse, "oracle_mask",
-                                                                            rounds=rounds, lanes=lanes))):
+        for name, fn in (("fq_driver", lambda st: fq_driver.run(os.path.join(tmp, "db"), imset, os.path.join(tmp, "fq"), prop, fuse, rounds=rounds, lanes=lanes, stats=st)),
+                         ("eval_driver_oracle_mask", lambda st: eval_driver.run(os.path.join(tmp, "db"), imset, os.path.join(tmp, "e.csv"), prop, fuse, "oracle_mask",
+                                                                                rounds=rounds, lanes=lanes, stats=st))):
             torch.cuda.synchronize()
+            st = {}
             t0 = time.perf_counter()
-            rows = fn()
+            rows = fn(st)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
-            out[name] = {"rounds": int(len(rows)), "seconds": dt, "rounds_per_s": len(rows) / dt, "propagated_frames_per_s": len(rows) * (frames - 1) / dt}
+            # propagated frames = what the engines' do_pass really visited (stcn_get_stats per interaction): rounds >= 2 walk only the spans
+            # between the new annotation and its neighbours (round 5 multiplied rounds by T - 1: 4-5 x too many)
+            out[name] = {"rounds": int(len(rows)), "seconds": dt, "rounds_per_s": len(rows) / dt, "propagated_frames": int(st.get("propagated_frames", 0)),
+                         "propagated_frames_per_s": st.get("propagated_frames", 0) / dt, "frames_per_round_mean": st.get("propagated_frames", 0) / max(len(rows), 1)}
         out["what"] = ("rounds/s incl. JPEG decode, H2D, propagation (1 first + 7 later interactions per sample), GPU J / J&F and all output files; "
                        "reference counterparts: generate_fq_dataset.py:60-86, eval_annotation_method.py:118-190 with interactions/mask.py:113-146")
         return out
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
         torch.cuda.empty_cache()
+
+
+def session_leg(prop, fuse, H, W, T, rounds, metric, videos=4, lanes_list=(1, 2, 4), tag=""):
+    """A SESSION-shaped number (BASELINE configs 4 / 5 are annotation sessions, not single first interactions): `videos` resident 480p clips,
+    each through `rounds` rounds of the reference's oracle mask policy (interactions/mask.py:113-146 via eva_vos_amd.eval_driver.run_policy:
+    one first interaction, then short fused spans; J or J&F per frame on the device after every round, annotated frames counting with their
+    ground truth) on a fresh InferenceCore per sample, as generate_fq_dataset.py:63-70 / interactions/mask.py:24-26 build them.  Clips, ground
+    truth and weights are resident before the timed region (no JPEG decode, no output files: the `drivers` leg has those).  Reported per lane
+    count: rounds/s, TRUE propagated frames/s (the engines' own visit counts) and `device_busy_frac` = kernel ms the same sessions need
+    (HIP events per launch, one profiled pass) / wall time."""
+    import threading
+    from eva_vos_amd import eval_driver, synth
+    from mivos.inference_core import InferenceCore
+    base = synth.synthetic_clip(T, H, W, seed=7).cuda()
+    gt = synth.synthetic_mask(T, H, W, 1, seed=7)                        # [1,T,1,H,W]
+    samples = []
+    for v in range(videos):
+        g = torch.Generator(device="cuda").manual_seed(9000 + v)
+        clip = base if v == 0 else base + 0.15 * torch.randn(base.shape, generator=g, device="cuda")
+        samples.append({"rgb": clip, "gt": gt.cuda(), "num_frames": T, "name": f"s{v}"})
+    torch.cuda.synchronize()
+
+    def one(sample, eo, prof=False):
+        core = InferenceCore(prop, fuse, sample["rgb"], 1, engine_options=eo)
+        kms = [0.0]
+        if prof:
+            core.set_profiling(True)
+            inner = core.interact
+
+            def interact(*a_, **k_):                                     # kernel ms of every interaction of the session (syncs: profiled pass only)
+                r_ = inner(*a_, **k_)
+                kms[0] += sum(v["ms"] for c, v in core.kernel_profile().items() if c != "conv_hbm_bound")
+                return r_
+            core.interact = interact
+        res = eval_driver.run_policy("oracle_mask", core, sample, rounds, metric)
+        return len(res["mu_metrics"]), res["propagated_frames"], kms[0], res["frames"]
+
+    def region(lanes, prof=False):
+        eo = {"lookahead": 0} if lanes > 1 else {"lookahead": 2}
+        dev = torch.cuda.current_device()
+        parts = [samples[l::lanes] for l in range(lanes)]
+        acc = [[0, 0, 0.0] for _ in range(lanes)]
+        picks = [None] * lanes
+
+        def lane(l):
+            torch.cuda.set_device(dev)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                for smp in parts[l]:
+                    r_, f_, k_, fr_ = one(smp, eo, prof)
+                    acc[l][0] += r_; acc[l][1] += f_; acc[l][2] += k_
+                    picks[l] = fr_
+                torch.cuda.current_stream().synchronize()
+
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        th = [threading.Thread(target=lane, args=(l,)) for l in range(lanes)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return dt, sum(a_[0] for a_ in acc), sum(a_[1] for a_ in acc), sum(a_[2] for a_ in acc), picks[0]
+
+    region(1)                                                            # warm-up: first launches of the rounds >= 2 kernels, pool
+    _, n_r, n_f, kms, picks = region(1, prof=True)
+    out = {"workload": f"{videos} resident {H}x{W} clips x {T} frames, k=1, mem_freq=5: {rounds} rounds of the oracle mask policy per clip (metric {metric}), "
+                       f"fresh InferenceCore per clip, per-frame {metric} on the device after every round {tag}".strip(),
+           "rounds_total": n_r, "propagated_frames_total": n_f, "frames_per_round_mean": n_f / max(n_r, 1),
+           "kernel_ms_total_profiled_pass": kms, "kernel_ms_per_propagated_frame": kms / max(n_f, 1),
+           "annotated_frames_first_clip": [int(v) for v in picks[:rounds]], "lanes": {}}
+    for lanes in lanes_list:
+        if lanes > videos:
+            continue
+        best = None
+        for _ in range(2):                                               # two passes, the faster one (50-500 ms regions)
+            dt, r_, f_, _, _ = region(lanes)
+            if best is None or dt < best[0]:
+                best = (dt, r_, f_)
+        dt, r_, f_ = best
+        out["lanes"][str(lanes)] = {"seconds": dt, "rounds_per_s": r_ / dt, "propagated_frames_per_s": f_ / dt, "device_busy_frac": kms * 1e-3 / dt}
+    one_lane = out["lanes"].get("1")
+    if one_lane:
+        out.update(rounds_per_s_one_lane=one_lane["rounds_per_s"], device_busy_frac_one_lane=one_lane["device_busy_frac"])
+    del samples, base
+    torch.cuda.empty_cache()
+    return out
 
 
 def launch_ranks(n):
@@ -923,6 +1024,14 @@ def main():
             cfg3["mask_iou_vs_cpu_oracle"] = cfg3["parity_vs_cpu_oracle"]["mask_iou_vs_cpu_oracle"]
         del prop3, fuse3
     mr_roof = memread_roofline(a.config3_objects) if (a.memread_roofline and world == 1) else None
+    ses = None
+    if a.session and world == 1 and real is None and rank == 0 and K_OBJ == 1:
+        try:
+            ses = {"config4_shape": session_leg(prop, fuse, H, W, 40, 8, "j", a.session_videos, tag="(generate_fq_dataset.py:69: 8 rounds, selection by J)"),
+                   "config5_shape": session_leg(prop, fuse, H, W, 66, 60, "j_and_f", max(2, a.session_videos // 2), lanes_list=(1, 2),
+                                                tag="(eval_annotation_method.py:30: 60 rounds, J&F)")}
+        except Exception as ex:                                   # an extra leg: never fail the line for it
+            ses = {"error": f"{type(ex).__name__}: {ex}"}
     drv = None
     if a.drivers and world == 1 and real is None and rank == 0:
         try:
@@ -969,6 +1078,8 @@ def main():
                        "weights": "model_weights/mivos/stcn.pth + fusion.pth" if real is not None else "synthetic recipe seed 0 (no checkpoints offline)"},
             "ms_per_frame": 1e3 * dt_all / (frames_all / world),
             "jf_rows_rank_J_F_JF": rows.round(4).tolist(),
+            # the path's one exchange step really ran over every rank: rows the gather returned, and the backend that carried it ("nccl" = RCCL)
+            "ranks_seen": int(len(rows)), "backend": (dist.get_backend() if dist is not None else None),
             "concurrent_videos_bit_identical": bool(lanes_identical),
             "power": power,
             "value_repeats": {"frames_per_s": [round(v, 2) for v in rep_rates], "min": min(rep_rates), "median": sorted(rep_rates)[len(rep_rates) // 2],
@@ -1045,9 +1156,17 @@ def main():
                                            "what": "conv launches under 19.7 FLOP/B of algorithmic intensity (1x1 channel expansions, stems)"}}
             # HBM-side bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate runs)
             try:
-                pmc_file = [f for f in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
+                import glob
+                pmc_file = os.path.basename(sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))[-1])
                 pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
+                from eva_vos_amd import _lib as _l
                 out["roofline"]["traffic"] = pmc["conv_gemm_traffic_bytes_per_launch"]
+                # is the committed capture a capture of THIS library?  (csrc hash stamped into the .so by the Makefile and into the capture by
+                # tools/refresh_profiles.sh; a capture from before round 6 has no hash and counts as stale)
+                out["roofline"]["traffic_commit"] = pmc.get("commit", "unknown")
+                out["roofline"]["traffic_csrc_hash"] = pmc.get("csrc_hash")
+                out["roofline"]["library_csrc_hash"] = _l.src_hash()
+                out["roofline"]["traffic_stale"] = pmc.get("csrc_hash") != _l.src_hash()
                 out["roofline"]["traffic_source"] = (f"profiles/{pmc_file}: a committed capture, NOT measured by this run (rocprofv3 --pmc passes of this "
                                                      f"workload at T={pmc.get('frames', 30)}, FETCH_SIZE x2 + WRITE_SIZE per conv GEMM launch; captured at commit "
                                                      f"{pmc.get('commit', 'unknown')}: {pmc.get('captured', 'round 2')})")
@@ -1075,6 +1194,8 @@ def main():
             out["config3"] = cfg3
         if mr_roof is not None:
             out["roofline_memread"] = mr_roof
+        if ses is not None:
+            out["session"] = ses
         if drv is not None:
             out["drivers"] = drv
         if world == 1 and a.cpu_frames > 1:

@@ -95,3 +95,25 @@ def check(rc: int, what: str = "stcn") -> None:
     if rc != 0:
         msg = lib().stcn_last_error()
         raise RuntimeError(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")
+
+
+def src_hash() -> str:
+    """The source hash the LOADED library was built from (csrc/Makefile: sha256 of the sorted *.hip / *.cpp / *.h of csrc + the C-ABI header +
+    the extra flags, 12 hex digits) - captures under profiles/ are stamped with it, bench.py compares it with theirs."""
+    import re
+    m = re.search(r"src ([0-9a-f]{12})", lib().stcn_version().decode())
+    return m.group(1) if m else "unknown"
+
+
+def tree_hash(extra: str = "") -> str:
+    """The same hash computed from the sources in the tree (what a fresh `make` would stamp): differs from src_hash() when the .so is stale."""
+    import glob
+    import hashlib
+    csrc = os.path.join(_HERE, "csrc")
+    files = sorted(os.path.basename(f) for pat in ("*.hip", "*.cpp", "*.h") for f in glob.glob(os.path.join(csrc, pat)))
+    h = hashlib.sha256()
+    for f in files:
+        h.update(open(os.path.join(csrc, f), "rb").read())
+    h.update(open(os.path.join(_HERE, "..", "include", "stcn_hip.h"), "rb").read())
+    h.update((extra + "\n").encode())
+    return h.hexdigest()[:12]

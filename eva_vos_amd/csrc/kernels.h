@@ -105,7 +105,8 @@ int wino_plan_splitk(const ConvP &p, size_t slab_floats);
 void wino_transform_weights(const float *w, int N, int Cin, int Kp, float *U);
 // fewest input channels of an F(4x4) layer.  64 (8 k-blocks, one K piece) since round 5: the 64-channel 3x3 convs of the value encoder's
 // ResNet-18 layer1 over the objects of a multi-object engine (129 600 rows at k = 5) take 56 instead of 98 us each - config 3 219 -> 224 frames/s;
-// at one object they have 52 workgroups and stay on the direct kernel (wino4_min_wg).  The key encoder's 64-channel convs are not flagged.
+// at one object they have 52 workgroups and stay on the direct kernel (wino4_min_wg).  The key encoder's 64-channel res2 convs are flagged too since the
+// key trunk moved to F(4x4) (engine.cpp wino4_layer; STCN_WINO4_KEY=0 at model creation takes the whole key trunk off F(4x4) again).
 #ifndef W4_MIN_CIN
 #define W4_MIN_CIN 64
 #endif

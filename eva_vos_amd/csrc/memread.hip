@@ -423,6 +423,11 @@ __global__ __launch_bounds__(256) void threshold_kernel(const float *__restrict_
 // provisional cut are scored again in fp64 from the key rows themselves (a handful of 256-byte rows for ~4 % of the queries) and the
 // cut is taken in that order: the selection is then the top-50 of the EXACT scores wherever fp32 could not tell, i.e. one error source
 // (ours) less in the comparison with any other implementation.  Softmax weights keep the fp32 scores (prop_net.py:53-60 in fp32).
+// Scope of "exact" (advisor, round 5): every (chunk, query) list reaches this kernel cut to its best TOPK by fp32 score (chunk write-out of
+// affinity_tile_kernel, and the rare overflow cut-back inside pass 2).  A row a few ulps below ITS CHUNK's 50th therefore never gets here; that
+// only matters when one chunk alone holds >= 50 candidates at or above the global cut - a single-chunk read (small banks), or a top-50
+// concentrated in one chunk.  There the selection is a valid fp32 top-50 and the re-score changes nothing; wherever the near-tie candidates
+// survive the per-chunk cut (the usual case: the engine's reads span several chunks and the top-50 several frames) it is the exact order.
 __device__ __forceinline__ double shfl_f64(double v, int src) {
     const long long b = __double_as_longlong(v);
     const int lo = __shfl((int)(b & 0xffffffffll), src), hi = __shfl((int)(b >> 32), src);

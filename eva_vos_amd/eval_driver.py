@@ -89,11 +89,13 @@ def run_policy(policy: str, processor, sample, rounds: int, metric: str = "j_and
     rng = rng or random
     frames, q = [0], None
     mus, times, per_round = [], [MASK_SECONDS], []
+    propagated = 0                                                 # frames the engine really visited (rounds >= 2 only walk the spans next to the new annotation)
     for r in range(1, rounds + 1):
         if r >= T or (q is not None and _exhausted(q, frames, T)):
             continue
         f = frames[r - 1]
         processor.interact(gt[f][None], f, download=False)
+        propagated += processor.stats()["frames"]
         mu, gen, q = frame_quality(processor, gt_thw, frames, metric)
         mus.append(mu)
         per_round.append(q.copy())
@@ -108,13 +110,14 @@ def run_policy(policy: str, processor, sample, rounds: int, metric: str = "j_and
             sel = _upper_bound_frame(processor, gt, gt_thw, frames, metric)
         times.append(SKIP_SECONDS if q[sel] == NO_OBJECT else MASK_SECONDS)
         frames.append(sel)
-    return dict(mu_metrics=mus, annotation_times=times[:-1], frames=frames, round_metrics=per_round)
+    return dict(mu_metrics=mus, annotation_times=times[:-1], frames=frames, round_metrics=per_round, propagated_frames=propagated)
 
 
 def run(root: str, imset: str, out_csv: str, prop_net, fuse_net, policy: str = "oracle_mask", rounds: int = 60,
-        metric: str = "j_and_f", qnet=None, seed: int = 0, device: str = "cuda", lanes: int = 2):
+        metric: str = "j_and_f", qnet=None, seed: int = 0, device: str = "cuda", lanes: int = 2, stats: dict = None):
     """Process this rank's share of the samples (`lanes` videos in flight); returns the gathered rows on every rank
-    (rows: sample id, round, mu_metric, annotation_time, annotated frame, T, then T per-frame values, NaN-padded)."""
+    (rows: sample id, round, mu_metric, annotation_time, annotated frame, T, then T per-frame values, NaN-padded).
+    `stats` (optional dict): this rank's `propagated_frames` (frames the engines visited) and `interactions` are added to it."""
     import torch.distributed as dist
 
     from mivos.inference_core import InferenceCore
@@ -124,11 +127,16 @@ def run(root: str, imset: str, out_csv: str, prop_net, fuse_net, policy: str = "
     t_max = max(s[2] for s in ds.samples)
     mine = sorted(shard.lpt_assign([s[2] for s in ds.samples], world)[rank])
     width = 6 + t_max
+    stats_lock = __import__("threading").Lock()
 
     def work(i, sample):
         rows = []
         proc = InferenceCore(prop_net, fuse_net, sample["rgb"], 1, engine_options=lane_engine_options(lanes))
         res = run_policy(policy, proc, sample, rounds, metric, qnet, random.Random(seed * 100003 + i))
+        if stats is not None:
+            with stats_lock:
+                stats["propagated_frames"] = stats.get("propagated_frames", 0) + res["propagated_frames"]
+                stats["interactions"] = stats.get("interactions", 0) + len(res["mu_metrics"])
         for r, (mu, sec, q) in enumerate(zip(res["mu_metrics"], res["annotation_times"], res["round_metrics"])):
             row = np.full(width, np.nan, np.float32)
             row[:6] = (i, r, mu, sec, res["frames"][r], len(q))

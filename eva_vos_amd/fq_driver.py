@@ -234,8 +234,9 @@ def per_frame_j(processor, gt_dev: torch.Tensor, interacted: List[int]) -> tuple
     return q, gen.to(torch.uint8)
 
 
-def oracle_rounds(processor, sample, rounds: int = 8):
-    """The oracle annotation policy of the FQ dataset (interactions/mask.py:113-156)."""
+def oracle_rounds(processor, sample, rounds: int = 8, stats: dict = None):
+    """The oracle annotation policy of the FQ dataset (interactions/mask.py:113-156).  `stats` (optional dict, one per caller thread):
+    the frames the engine really visited (`propagated_frames`) and the `interactions` are added to it."""
     T = sample["num_frames"]
     gt = sample["gt"][0].to(processor.prob.device)              # [T,1,H,W]
     gt_thw = gt[:, 0]
@@ -247,6 +248,9 @@ def oracle_rounds(processor, sample, rounds: int = 8):
             continue
         f = frames[r - 1]
         processor.interact(gt[f][None], f, download=False)         # [1,1,H,W] mask of the annotated frame
+        if stats is not None:
+            stats["propagated_frames"] = stats.get("propagated_frames", 0) + processor.stats()["frames"]
+            stats["interactions"] = stats.get("interactions", 0) + 1
         quality, gen = per_frame_j(processor, gt_thw, frames[:r])
         worst = int(np.argmin(quality))
         frames.append(worst)
@@ -319,9 +323,10 @@ def save_rgb_frames(rgb: torch.Tensor, out_dir: str, pool=None):
 
 
 def run(root: str, imset: str, out: str, prop_net, fuse_net, rounds: int = 8, save_masks: bool = True,
-        device: str = "cuda", lanes: int = 2):
+        device: str = "cuda", lanes: int = 2, stats: dict = None):
     """Process this rank's share of the samples (`lanes` videos in flight); returns the gathered rows on every rank
-    (rows: sample id, round, selected frame, T, then T per-frame J values padded with NaN)."""
+    (rows: sample id, round, selected frame, T, then T per-frame J values padded with NaN).
+    `stats` (optional dict): this rank's `propagated_frames` (frames the engines visited) and `interactions` are added to it."""
     import torch.distributed as dist
     from concurrent.futures import ThreadPoolExecutor
 
@@ -347,7 +352,12 @@ def run(root: str, imset: str, out: str, prop_net, fuse_net, rounds: int = 8, sa
             if first:
                 pending.append(save_rgb_frames(sample["rgb"][0], os.path.join(out, "RGBFrames", "224", sample["video"]), writers))
         proc = InferenceCore(prop_net, fuse_net, sample["rgb"], 1, engine_options=lane_engine_options(lanes))
-        states, gens = oracle_rounds(proc, sample, rounds)
+        mine_stats = {} if stats is not None else None
+        states, gens = oracle_rounds(proc, sample, rounds, mine_stats)
+        if stats is not None:
+            with rgb_lock:
+                for k_, v_ in mine_stats.items():
+                    stats[k_] = stats.get(k_, 0) + v_
         sid = 1
         for r, ((worst, q), gen) in enumerate(zip(states, gens)):
             if float(q[worst]) == NO_OBJECT:

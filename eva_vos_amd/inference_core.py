@@ -24,11 +24,20 @@ from . import _lib
 _MODEL_CACHE: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
 _PINNED_DOWNLOAD = os.environ.get("STCN_PINNED_DOWNLOAD", "1") != "0"      # 0: the reference's plain .cpu() (measurement aid)
 # interact() returns its masks in a PINNED host block that the returned array owns (one DMA instead of a staged copy).  A caller that keeps
-# every round's result - the reference-style loops do - would pile up page-locked memory (27 MB per 66-frame 480p clip): at most this many
-# pinned result blocks are alive per process at a time; beyond that a result comes back in pageable memory, as the reference's .cpu() does.
-_PINNED_MAX_LIVE = int(os.environ.get("STCN_PINNED_MAX_LIVE", "8"))
-_PINNED_LIVE: list = []
-_PINNED_LOCK = threading.Lock()
+# every round's result - the reference-style loops do - would pile up page-locked memory (27 MB per 66-frame 480p clip).  The budget is
+# PER CORE (round 6; a process-wide count of 8 was smaller than the working set of bench.py's own 8 engines, whose later downloads silently
+# went pageable): at most _PINNED_MAX_LIVE result blocks of one core are alive at a time, and at most STCN_PINNED_MAX_MB of page-locked result
+# memory per process; beyond either a result comes back in pageable memory, as the reference's .cpu() does.  pageable_downloads() counts those.
+_PINNED_MAX_LIVE = int(os.environ.get("STCN_PINNED_MAX_LIVE", "4"))
+_PINNED_MAX_BYTES = int(float(os.environ.get("STCN_PINNED_MAX_MB", "4096")) * (1 << 20))
+_PINNED_BYTES = [0]                  # page-locked result bytes alive in this process
+_PAGEABLE_DOWNLOADS = [0]            # interact() downloads that went through pageable memory (budget exhausted or STCN_PINNED_DOWNLOAD=0)
+_PINNED_LOCK = threading.RLock()          # re-entrant: a block's __del__ may run (GC) on a thread that holds it
+
+
+def pageable_downloads() -> int:
+    """How many interact() downloads of this process did NOT get a pinned block (a measurement aid: bench.py prints it)."""
+    return _PAGEABLE_DOWNLOADS[0]
 
 
 class _PinnedBlock:
@@ -36,22 +45,39 @@ class _PinnedBlock:
     ``__array_interface__`` as the array's base, so the block - and the weak reference that counts it - lives exactly as long as the
     array or any view of it.  (A weak reference to the tensor itself dies as soon as the Python wrapper is dropped, whatever still
     holds the storage.)"""
-    __slots__ = ("tensor", "__array_interface__", "__weakref__")
+    __slots__ = ("tensor", "nbytes", "__array_interface__", "__weakref__")
 
     def __init__(self, tensor):
         self.tensor = tensor
+        self.nbytes = tensor.numel()
         self.__array_interface__ = {"shape": tuple(tensor.shape), "typestr": "|u1", "data": (tensor.data_ptr(), False), "version": 3}
 
+    def __del__(self):
+        with _PINNED_LOCK:
+            _PINNED_BYTES[0] -= self.nbytes
 
-def _pinned_result(shape):
-    """A pinned uint8 result block, or None when _PINNED_MAX_LIVE earlier results are still held by their arrays."""
+
+def _pinned_result(shape, live: list):
+    """A pinned uint8 result block, or None when the core's `live` list (weak references to its earlier blocks) still holds
+    _PINNED_MAX_LIVE blocks kept alive by their arrays, or the process holds STCN_PINNED_MAX_MB of them."""
+    nbytes = int(np.prod(shape))
     with _PINNED_LOCK:
-        _PINNED_LIVE[:] = [r for r in _PINNED_LIVE if r() is not None]
-        if len(_PINNED_LIVE) >= _PINNED_MAX_LIVE:
+        live[:] = [r for r in live if r() is not None]
+        if len(live) >= _PINNED_MAX_LIVE or _PINNED_BYTES[0] + nbytes > _PINNED_MAX_BYTES:
+            _PAGEABLE_DOWNLOADS[0] += 1
             return None
-        block = _PinnedBlock(torch.empty(shape, dtype=torch.uint8, pin_memory=True))
-        _PINNED_LIVE.append(weakref.ref(block))
-        return block
+        _PINNED_BYTES[0] += nbytes
+    try:
+        host = torch.empty(shape, dtype=torch.uint8, pin_memory=True)
+    except RuntimeError:                                            # the host refuses more page-locked memory: pageable, as beyond the budget
+        with _PINNED_LOCK:
+            _PINNED_BYTES[0] -= nbytes
+            _PAGEABLE_DOWNLOADS[0] += 1
+        return None
+    block = _PinnedBlock(host)
+    with _PINNED_LOCK:
+        live.append(weakref.ref(block))
+    return block
 
 
 class _Model:
@@ -202,6 +228,7 @@ class InferenceCore:
         self._finalizer = weakref.finalize(self, _lib.lib().stcn_engine_destroy, h_)
         self.interacted = set()
         self.last_enqueue_s = 0.0
+        self._pinned_live = []                                     # weak references to this core's pinned result blocks still held by arrays
 
     # ------------------------------------------------------------------------------------------
     def interact(self, mask, idx, scribble=False, download=True):
@@ -228,7 +255,8 @@ class InferenceCore:
                 return None
             lw, uw, lh, uh = self.pad
             out = self.masks[:, 0, lh:self.nh - uh, lw:self.nw - uw]
-            block = _pinned_result(out.shape) if _PINNED_DOWNLOAD else None
+            self.np_masks = None                                    # the previous result no longer counts against this core's budget (unless the caller kept it)
+            block = _pinned_result(out.shape, self._pinned_live) if _PINNED_DOWNLOAD else None
             if block is not None:
                 host = block.tensor
                 # D2H into PINNED host memory (PyTorch's caching host allocator hands the 27 MB block of a 66-frame 480p clip back and
@@ -239,6 +267,8 @@ class InferenceCore:
                 torch.cuda.current_stream().synchronize()
                 self.np_masks = np.asarray(block)
             else:
+                if not _PINNED_DOWNLOAD:
+                    _PAGEABLE_DOWNLOADS[0] += 1
                 self.np_masks = out.cpu().numpy().astype(np.uint8, copy=False)     # D2H sync, as the reference's .cpu(); a fresh array per call
         return self.np_masks
 
@@ -312,14 +342,14 @@ class InferenceCore:
     def __deepcopy__(self, memo):
         new = object.__new__(InferenceCore)
         for k, v in self.__dict__.items():
-            if k in ("_engine", "_finalizer", "prob", "masks", "np_masks", "interacted"):
+            if k in ("_engine", "_finalizer", "prob", "masks", "np_masks", "interacted", "_pinned_live"):
                 continue
             new.__dict__[k] = v                                   # nets, model handle, images: shared (read-only)
         with torch.cuda.device(self.device):
             self._leave_engine_stream(torch.cuda.current_stream())     # the clones below read what the engine stream wrote
             torch.cuda.current_stream().synchronize()
             new.prob, new.masks = self.prob.clone(), self.masks.clone()
-            new.np_masks, new.interacted = self.np_masks.copy(), set(self.interacted)
+            new.np_masks, new.interacted, new._pinned_live = self.np_masks.copy(), set(self.interacted), []
             new._stream = torch.cuda.current_stream()
             h_ = C.c_void_p()
             _lib.check(_lib.lib().stcn_engine_clone(self._engine, new.prob.data_ptr(), new.masks.data_ptr(),

@@ -95,7 +95,18 @@ def frame_miss(a, b, min_union=64):
     return float(miss.max()), int(miss.argmax())
 
 
+# Allowance over the reference's own spread (round 6: 1.5, was 3 - a 3 x allowance would hide a 3 x regression; measured HIP-vs-oracle
+# differences sit at ~1.0 x the reference's thread-count noise, so 1.5 x is margin for which near-ties happen to flip, not for drift)
+NOISE_X = 1.5
+
+
 def frame_bound(noise_col4, union_px):
-    """Per-frame mask bound: the north_star 1e-3, or 3 x the reference's own worst per-frame difference between its 1/2/4/8-
+    """Per-frame mask bound: the north_star 1e-3, or NOISE_X (1.5) x the reference's own worst per-frame difference between its 1/2/4/8-
     thread runs on that fixture (tests/golden/selfnoise.npz, column 4), or - small objects - two pixels, whichever is larger."""
-    return max(1e-3, 3.0 * float(noise_col4), 2.0 / max(float(union_px), 1.0))
+    return max(1e-3, NOISE_X * float(noise_col4), 2.0 / max(float(union_px), 1.0))
+
+
+def clip_bound(noise_col0=0.0):
+    """Per-object mask bound on a whole clip (1 - IoU): the north_star 1e-3; only where the reference's OWN clip-level spread on the
+    nearest fixture exceeds it / NOISE_X (small frames with k > 1: 1.16e-3 on seqC / seqD, saturated aggregation) NOISE_X x that."""
+    return max(1e-3, NOISE_X * float(noise_col0))

@@ -14,7 +14,7 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 SMALL = ["--steps", "2", "--warmup", "0", "--frames", "12", "--height", "240", "--width", "432", "--streams", "1",
-         "--no-profile", "--no-r2", "--cpu-frames", "0", "--no-config3", "--no-memread-roofline", "--no-davis-val", "--no-drivers", "--no-power"]
+         "--no-profile", "--no-r2", "--cpu-frames", "0", "--no-config3", "--no-memread-roofline", "--no-davis-val", "--no-drivers", "--no-session", "--no-power"]
 
 
 def run_bench(args, env_extra=None):
@@ -81,7 +81,7 @@ def test_davis_val_workload_is_sharded_by_lpt_over_the_ranks():
 
 
 TINY = ["--warmup", "0", "--frames", "5", "--height", "128", "--width", "160", "--streams", "1", "--no-profile", "--no-r2",
-        "--cpu-frames", "0", "--no-config3", "--no-memread-roofline", "--no-drivers", "--no-power"]
+        "--cpu-frames", "0", "--no-config3", "--no-memread-roofline", "--no-drivers", "--no-session", "--no-power"]
 
 
 def test_eight_rank_preflight_on_one_device():

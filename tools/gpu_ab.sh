@@ -11,7 +11,7 @@ for rep in 1 2 3; do
     i=$((i+1))
     for s in ${STREAMS:-4 1}; do
       if [ "$arm" = "-" ]; then envs=""; else envs="$arm"; fi
-      env $envs python bench.py --streams $s --steps ${STEPS:-24} --warmup 4 --cpu-frames 0 --no-r2 --no-config3 --no-memread-roofline --no-davis-val --no-drivers --no-power --value-repeats 1 --no-profile > $O/b.json 2> $O/b.err
+      env $envs python bench.py --streams $s --steps ${STEPS:-24} --warmup 4 --cpu-frames 0 --no-r2 --no-config3 --no-memread-roofline --no-davis-val --no-drivers --no-session --no-power --value-repeats 1 --no-profile > $O/b.json 2> $O/b.err
       python - <<PY
 import json
 l=[x for x in open("$O/b.json") if x.startswith("{")]

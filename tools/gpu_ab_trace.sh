@@ -13,7 +13,7 @@ for rep in 1 2 3; do
     i=$((i+1))
     if [ "$arm" = "-" ]; then envs="X_=1"; else envs="$arm"; fi
     export $envs
-    STCN_LOOKAHEAD=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/a${i}_$rep -o r -- python3 $R/bench.py --streams 1 --steps 2 --warmup 1 --no-profile --cpu-frames 0 --no-r2 --no-config3 --no-memread-roofline --no-davis-val --no-drivers --no-power --value-repeats 1 > $O/log 2>&1
+    STCN_LOOKAHEAD=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/a${i}_$rep -o r -- python3 $R/bench.py --streams 1 --steps 2 --warmup 1 --no-profile --cpu-frames 0 --no-r2 --no-config3 --no-memread-roofline --no-davis-val --no-drivers --no-session --no-power --value-repeats 1 > $O/log 2>&1
     for e in $envs; do unset ${e%%=*}; done
     echo "rep $rep arm $i [$arm]: $(python3 $R/tools/kstat.py $O/a${i}_$rep $K | awk -v k="$K" 'NR==1{t=$4} NR>1{s+=$1} END{printf "total %s ms, %s kernels %.2f ms", t, k, s}')"
     find $O/a${i}_$rep -name "*kernel_trace.csv" -delete

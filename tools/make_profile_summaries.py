@@ -169,7 +169,8 @@ traffic = sum(kernels[k]["traffic_bytes_per_launch"] * kernels[k]["calls"] for k
 wk = [k for k in kernels if "wino" in k and "_input_kernel" in k]
 out = dict(command="rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) --kernel-trace -- python3 bench.py --steps 1 --warmup 0 --streams 1 "
                    "--no-profile --frames 30 --cpu-frames 0 --no-r2 --no-config3 --no-memread-roofline --no-davis-val (STCN_LOOKAHEAD=0)",
-           commit=commit, frames=30, captured=f"{tag}, tools/refresh_profiles.sh",
+           commit=commit, csrc_hash=(open(os.path.join(SRC, "csrc_hash.txt")).read().strip() if os.path.exists(os.path.join(SRC, "csrc_hash.txt")) else None),
+           frames=30, videos_in_capture=2, captured=f"{tag}, tools/refresh_profiles.sh",
            units="counter values are KB per the rocprofv3 derived metric; gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reads 1/2 of the "
                  "bytes of wide (16 B/lane) coalesced reads -> doubled; WRITE_SIZE exact; Infinity-Cache hits are included (fabric-side counters)",
            conv_gemm_traffic_bytes_per_launch=traffic, conv_gemm_launches=n,

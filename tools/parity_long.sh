@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/parity_long
 rm -rf $O; mkdir -p $O
 cd $R
-Q="--steps 4 --no-profile --no-r2 --no-memread-roofline --no-davis-val --no-drivers --value-repeats 1 --parity-long-frames 0"
+Q="--steps 4 --no-profile --no-r2 --no-memread-roofline --no-davis-val --no-drivers --no-session --value-repeats 1 --parity-long-frames 0"
 python bench.py $Q --no-config3 --parity-session-rounds ${ROUNDS:-24} > $O/session.log 2> $O/session.err
 python bench.py $Q --cpu-frames 0 --config3-oracle-frames ${C3FRAMES:-104} > $O/config3.log 2> $O/config3.err
 python - <<PY

@@ -12,7 +12,7 @@ sample() {   # $1 = output file, runs until the file $O/stop exists
 rocm-smi --showpower --showclocks --showtemp --showmaxpower --json 2>/dev/null > $O/idle.txt
 rocm-smi --showmaxpower --showperflevel 2>/dev/null | grep -v "^$" | head -12
 rm -f $O/stop; sample $O/bench.txt & SP=$!
-python bench.py --streams 4 --steps 48 --warmup 4 --cpu-frames 0 --no-r2 --no-config3 --no-memread-roofline --no-davis-val --no-drivers --no-power --value-repeats 1 --no-profile 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('headline %.1f frames/s' % d['value'])"
+python bench.py --streams 4 --steps 48 --warmup 4 --cpu-frames 0 --no-r2 --no-config3 --no-memread-roofline --no-davis-val --no-drivers --no-session --no-power --value-repeats 1 --no-profile 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('headline %.1f frames/s' % d['value'])"
 touch $O/stop; wait $SP
 python - <<PY
 import json, re, statistics as st

@@ -9,9 +9,9 @@ O=$R/gpurun_out/prof_final
 rm -rf $O; mkdir -p $O
 cd $R
 SECONDS=0; python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench_default wall ${SECONDS} s" | tee $O/bench_default.wall
-python bench.py --streams 1 --cpu-frames 0 --no-profile --no-r2 --no-config3 --no-memread-roofline --no-davis-val --no-drivers --no-power 2>/dev/null | tail -1 > $O/bench_streams1.json
+python bench.py --streams 1 --cpu-frames 0 --no-profile --no-r2 --no-config3 --no-memread-roofline --no-davis-val --no-drivers --no-session --no-power 2>/dev/null | tail -1 > $O/bench_streams1.json
 cd /tmp && export TMPDIR=/tmp
-Q="--cpu-frames 0 --no-r2 --no-config3 --no-memread-roofline --no-davis-val --no-drivers --no-power --value-repeats 1"
+Q="--cpu-frames 0 --no-r2 --no-config3 --no-memread-roofline --no-davis-val --no-drivers --no-session --no-power --value-repeats 1"
 STCN_LOOKAHEAD=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o r -- python3 $R/bench.py --streams 1 --steps 2 --warmup 1 --no-profile $Q > $O/trace.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_default -o r -- python3 $R/bench.py $Q > $O/trace_default.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_memread -o r -- python3 $R/tools/memread_bench.py --k 5 > $O/trace_memread.log 2>&1
@@ -29,5 +29,6 @@ python3 $R/tools/mfma_busy.py $(find $O/pmcSQ -name "p_counter_collection.csv" |
 python3 $R/tools/memread_bench.py --k 1 > $O/memread_k1.txt 2>&1
 python3 $R/tools/wino4_ab_parity.py > $O/wino4_ab_parity.txt 2>&1
 find $O -name "r_kernel_trace.csv" -delete; find $O -name "p_kernel_trace.csv" -delete       # large, not needed for the summaries
+python3 -c "import sys; sys.path.insert(0, '$R'); from eva_vos_amd import _lib; print(_lib.src_hash())" > $O/csrc_hash.txt 2>/dev/null
 git -C $R rev-parse --short HEAD > $O/commit.txt 2>/dev/null || echo "${GRAFT_COMMIT:-unknown}" > $O/commit.txt
 ls -la $O | head -30
