@@ -172,6 +172,11 @@ struct stcn_engine {
     // key-encoder look-ahead: frames ahead of the decode chain are encoded on a side stream
     hipStream_t side = nullptr;
     stcn::Work work_side;
+    // round 6: a SECOND key-encoder stream (own workspace): consecutive key batches alternate between the two, so two encoder passes and the
+    // decode chain are in flight together - one video then fills the chip's kernel tails the way several lanes do (STCN_KEY_STREAMS=1: off)
+    hipStream_t side2 = nullptr;
+    stcn::Work work_side2;
+    int key_rr = 0;                      // which side stream takes the next key batch
     std::vector<hipEvent_t> key_ready;   // per frame: recorded on `side` after its encode_key
     std::vector<char> key_pending;       // per frame: main stream has not yet waited on key_ready
     int lookahead = 0;

@@ -306,6 +306,21 @@ int stcn_metrics_j_counts(void *stream, const uint8_t *gt_dev, const uint8_t *pr
     return STCN_OK;
 }
 
+int stcn_metrics_round(void *stream, const uint8_t *masks_dev, int nh, int nw, int lh, int lw, const uint8_t *gt_dev, const uint8_t *annotated_dev,
+                       const uint8_t *noobj_dev, int T, int H, int W, int j_only, double no_object, uint8_t *gen_dev, uint8_t *scratch_dev,
+                       int32_t *counts_dev, double *quality_dev, int32_t *select_dev) {
+    if (!masks_dev || !gt_dev || !annotated_dev || !noobj_dev || !gen_dev || !counts_dev || !quality_dev || !select_dev || (!j_only && !scratch_dev) ||
+        T < 1 || H < 2 || W < 2 || lh < 0 || lw < 0 || lh + H > nh || lw + W > nw) {
+        set_error("stcn_metrics_round: bad arguments");
+        return STCN_E_INVALID;
+    }
+    const int radius = j_only ? -1 : (int)std::ceil(0.008 * std::sqrt((double)H * H + (double)W * W));      // interactions/metrics.py:119-120
+    round_score_launch(masks_dev, nh, nw, lh, lw, gt_dev, annotated_dev, noobj_dev, T, H, W, radius, no_object, gen_dev, scratch_dev, counts_dev,
+                       quality_dev, select_dev, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return STCN_OK;
+}
+
 int stcn_bench_mfma_rate(void *stream, int ms_target, float *tflops, float *ms_out) {
     if (!tflops || ms_target < 1 || ms_target > 2000) { set_error("stcn_bench_mfma_rate: bad arguments"); return STCN_E_INVALID; }
     hipStream_t s = (hipStream_t)stream;

@@ -4,9 +4,13 @@
 // HBM-bound stencil work: one pass builds both 1-pixel boundary maps, a second pass visits the pixels and, ONLY
 // at boundary pixels (a few thousand per frame), scans the disk window of the other map; six integer counters per
 // frame are accumulated with integer atomics (exact, order-independent).
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace stcn {
+
+void jf_counts_launch(const uint8_t *gt, const uint8_t *pred, int T, int H, int W, int radius, uint8_t *bmap, int *counts, hipStream_t s);
 
 // Counting: a thread visits PPT pixels (a wave 64 consecutive pixels per step: coalesced byte loads), keeps its counters in registers
 // and the wave adds them up ONCE at the end - one integer atomic per wave and counter when the wave's 64 x PPT pixels lie inside one
@@ -121,6 +125,73 @@ __global__ __launch_bounds__(256) void jf_match_kernel(const uint8_t *__restrict
             if (c5) atomicAdd(&counts[t0 * 6 + 5], c5);
         }
     }
+}
+
+// ---- one annotation round on the device (round 6): compose -> counts -> quality + selection ------------------------------------------
+// gen[t] = the engine's mask of frame t (cropped out of the padded [T][nh][nw] tensor, non-zero = object), or the ground truth where the frame
+// is annotated (interactions/eval.py:57-60: annotated frames count with their GT mask).  gen is what util/fq_dataset.py:64-84 saves as a state.
+__global__ __launch_bounds__(256) void round_compose_kernel(const uint8_t *__restrict__ masks, int nh, int nw, int lh, int lw,
+                                                            const uint8_t *__restrict__ gt, const uint8_t *__restrict__ annotated, int T, int H, int W,
+                                                            uint8_t *__restrict__ gen) {
+    const long hw = (long)H * W, n = T * hw;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int t = (int)(i / hw);
+        const int rem = (int)(i - t * hw);
+        const int y = rem / W, x = rem - y * W;
+        gen[i] = annotated[t] ? (uint8_t)(gt[i] != 0) : (uint8_t)(masks[((long)t * nh + y + lh) * nw + x + lw] != 0);
+    }
+}
+
+// quality[t] in fp64 with the operations, and their order, of the host path (eva_vos_amd/metrics.py::_scores_from_counts, itself the
+// reference's interactions/metrics.py:141-158 / eval.py:62-79): J = inter / union (0 when the union is empty), F = 2 p r / (p + r) with the
+// reference's special cases, J&F = 0.5 (J + F); frames whose ground truth is empty get the NO_OBJECT token.  IEEE division / multiplication /
+// addition are correctly rounded on the device as on the host, so the values - and therefore the arg-min (first index of the minimum, as
+// numpy.argmin) - are bit-identical to the host path's.  One workgroup; T <= a few hundred.
+__global__ __launch_bounds__(256) void round_quality_kernel(const int *__restrict__ counts, const uint8_t *__restrict__ noobj, int T, int j_only,
+                                                            double no_object, double *__restrict__ quality, int *__restrict__ select) {
+    __shared__ double sv[256];
+    __shared__ int si[256];
+    double best = __builtin_inf();
+    int besti = 0x7fffffff;
+    for (int t = threadIdx.x; t < T; t += 256) {
+        const int *c = counts + t * 6;
+        const double j = c[1] == 0 ? 0.0 : __ddiv_rn((double)c[0], (double)c[1]);
+        double q = j;
+        if (!j_only) {
+            const int n_gt = c[2], n_fg = c[3];
+            double p, r;
+            if (n_fg == 0 && n_gt > 0) { p = 1.0; r = 0.0; }
+            else if (n_fg > 0 && n_gt == 0) { p = 0.0; r = 1.0; }
+            else if (n_fg == 0 && n_gt == 0) { p = 1.0; r = 1.0; }
+            else { p = __ddiv_rn((double)c[5], (double)n_fg); r = __ddiv_rn((double)c[4], (double)n_gt); }
+            const double s = __dadd_rn(p, r);
+            const double f = s == 0.0 ? 0.0 : __ddiv_rn(__dmul_rn(__dmul_rn(2.0, p), r), s);
+            q = __dmul_rn(0.5, __dadd_rn(j, f));
+        }
+        if (noobj[t]) q = no_object;
+        quality[t] = q;
+        if (q < best) { best = q; besti = t; }                               // ascending t per thread: the first minimum of its subsequence
+    }
+    sv[threadIdx.x] = best; si[threadIdx.x] = besti;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            const double v = sv[threadIdx.x + o]; const int i2 = si[threadIdx.x + o];
+            if (v < sv[threadIdx.x] || (v == sv[threadIdx.x] && i2 < si[threadIdx.x])) { sv[threadIdx.x] = v; si[threadIdx.x] = i2; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) select[0] = si[0];
+}
+
+void round_score_launch(const uint8_t *masks, int nh, int nw, int lh, int lw, const uint8_t *gt, const uint8_t *annotated, const uint8_t *noobj,
+                        int T, int H, int W, int radius, double no_object, uint8_t *gen, uint8_t *bmap, int *counts, double *quality, int *select,
+                        hipStream_t s) {
+    const long n = (long)T * H * W;
+    const unsigned blocks = (unsigned)std::min<long>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(round_compose_kernel, dim3(blocks), dim3(256), 0, s, masks, nh, nw, lh, lw, gt, annotated, T, H, W, gen);
+    jf_counts_launch(gt, gen, T, H, W, radius, bmap, counts, s);
+    hipLaunchKernelGGL(round_quality_kernel, dim3(1), dim3(256), 0, s, counts, noobj, T, radius < 0 ? 1 : 0, no_object, quality, select);
 }
 
 void jf_counts_launch(const uint8_t *gt, const uint8_t *pred, int T, int H, int W, int radius, uint8_t *bmap,

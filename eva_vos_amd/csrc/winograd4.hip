@@ -35,9 +35,32 @@ namespace stcn {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// DIAGNOSTIC build only (make EXTRA=-DSTCN_W4_CLOCK=1|2, tools/w4_clock.sh): wave 0 of every workgroup stamps s_memtime (shader cycles) and
+// s_memrealtime (100 MHz) around the main loop; quotient x 100 MHz = the clock the chip held INSIDE the loop (MI355X_MICROARCH.md, DVFS
+// give-back (6)).  =2 additionally replaces every MFMA by 16 v_fma_f32 on its accumulator registers: the same 64 issue cycles, the same
+// loads, no matrix arithmetic - separates "clock held down by the MFMAs' power" from "loop bound by operand feed".  The shipped library
+// executes no stamp.
+#ifdef STCN_W4_CLOCK
+__device__ unsigned long long g_w4_clock[2 * 8192];
+#if STCN_W4_CLOCK == 2
+#define W4_MFMA(a_, b_, c_) w4_fake_mfma(a_, b_, c_)
+#endif
+#endif
+#ifndef W4_MFMA
+#define W4_MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x2f32(a_, b_, c_, 0, 0, 0)
+#endif
+
 static constexpr int W4T = 32;       // tiles per workgroup
 static constexpr int W4N = 32;       // output channels per workgroup
 static constexpr int W4W = 12;       // waves per workgroup (3 positions each)
+
+#if defined(STCN_W4_CLOCK) && STCN_W4_CLOCK == 2
+__device__ __forceinline__ f32x16 w4_fake_mfma(float a, float b, f32x16 c) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(c[e]) : "v"(a), "v"(b));
+    return c;
+}
+#endif
 
 // 1-D input transform with the points {0, 3/4, -3/4, 3/2, -3/2, inf}: o = B^T d
 __device__ __forceinline__ void bt6(const f32x4 &d0, const f32x4 &d1, const f32x4 &d2, const f32x4 &d3, const f32x4 &d4, const f32x4 &d5,
@@ -202,8 +225,18 @@ __global__ __launch_bounds__(64 * W4W) void wino4_gemm_kernel(const Wino4G p, co
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int bi = 0; bi < MB; ++bi) acc[pi][bi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[bi][j], fb[j], acc[pi][bi], 0, 0, 0);
+            for (int bi = 0; bi < MB; ++bi) acc[pi][bi] = W4_MFMA(fa[bi][j], fb[j], acc[pi][bi]);
     };
+#ifdef STCN_W4_CLOCK
+    unsigned long long ck_t0 = 0, ck_r0 = 0;
+    if (wave == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        ck_t0 = __builtin_amdgcn_s_memtime();
+        ck_r0 = __builtin_amdgcn_s_memrealtime();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
     if (MB == 1) {
         // three fragment sets: the loads of k-block k+2 are issued before the MFMAs of k-block k (as wino_gemm_kernel)
         f32x4 fa[3][PPW][MB], fb[3][PPW];
@@ -218,7 +251,7 @@ __global__ __launch_bounds__(64 * W4W) void wino4_gemm_kernel(const Wino4G p, co
                 for (int pi = 0; pi < PPW; ++pi)
 #pragma unroll
                     for (int bi = 0; bi < MB; ++bi)
-                        acc[pi][bi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][pi][bi][j], fb[set][pi][j], acc[pi][bi], 0, 0, 0);
+                        acc[pi][bi] = W4_MFMA(fa[set][pi][bi][j], fb[set][pi][j], acc[pi][bi]);
         };
         load(0, 0);
         load(min(1, nk - 1), 1);
@@ -258,7 +291,7 @@ __global__ __launch_bounds__(64 * W4W) void wino4_gemm_kernel(const Wino4G p, co
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int pi = 0; pi < PPW; ++pi) acc[pi][bi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[pi][j], bb[pi][j], acc[pi][bi], 0, 0, 0);
+                for (int pi = 0; pi < PPW; ++pi) acc[pi][bi] = W4_MFMA(a[pi][j], bb[pi][j], acc[pi][bi]);
         };
         loadB(0, fb[0]);
         loadA(0, 0, fa[0]);
@@ -284,6 +317,15 @@ __global__ __launch_bounds__(64 * W4W) void wino4_gemm_kernel(const Wino4G p, co
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+#ifdef STCN_W4_CLOCK
+    if (wave == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long ck_t1 = __builtin_amdgcn_s_memtime(), ck_r1 = __builtin_amdgcn_s_memrealtime();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_sched_barrier(0);
+        if (lane == 0 && blockIdx.x < 8192) { g_w4_clock[2 * blockIdx.x] = ck_t1 - ck_t0; g_w4_clock[2 * blockIdx.x + 1] = ck_r1 - ck_r0; }
+    }
+#endif
     // ---- epilogue, 32 tiles at a time: all 36 positions of 32 x 32 (tile, channel) pairs meet in LDS, Y = A^T M A.
     // thread = (tile, 4 consecutive channels, half of the output columns): 16-byte LDS reads, residual loads and stores; the
     // first 8 waves work (32 tiles x 8 channel quads x 2 column pairs).  The residual block (+ bias) is requested before the
@@ -643,5 +685,12 @@ void wino4_transform_weights(const float *w, int N, int Cin, int Kp, float *U) {
                 }
         }
 }
+
+#ifdef STCN_W4_CLOCK
+// diagnostic build only: the per-workgroup stamp pairs of the LAST wino4_gemm_kernel launches (not part of the C ABI header)
+extern "C" int stcn_debug_w4_clock(unsigned long long *host_out, int n_pairs) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_w4_clock), (size_t)2 * (n_pairs < 8192 ? n_pairs : 8192) * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 }  // namespace stcn

@@ -87,20 +87,23 @@ def run_policy(policy: str, processor, sample, rounds: int, metric: str = "j_and
     gt_thw = gt[:, 0]
     images = sample["rgb"][0].to(dev) if policy == "qnet_mask" else None
     rng = rng or random
-    frames, q = [0], None
-    mus, times, per_round = [], [MASK_SECONDS], []
+    # the evaluation of a round stays on the device (metrics.RoundScorer): one int per round crosses PCIe for the oracle policy, the
+    # per-frame quality rows of the whole session are fetched once at the end
+    scorer = metrics.RoundScorer(gt_thw, "j" if metric == "j" else "j_and_f", max_rounds=max(rounds, 1), no_object=NO_OBJECT)
+    empty = scorer.empty_host
+    valid = set(np.where(~empty)[0].tolist())
+    frames, times, scored = [0], [MASK_SECONDS], 0
     propagated = 0                                                 # frames the engine really visited (rounds >= 2 only walk the spans next to the new annotation)
     for r in range(1, rounds + 1):
-        if r >= T or (q is not None and _exhausted(q, frames, T)):
+        if r >= T or (scored and not (valid - set(frames))):       # not_avail_frames (interactions/eval.py:84-89)
             continue
         f = frames[r - 1]
         processor.interact(gt[f][None], f, download=False)
         propagated += processor.stats()["frames"]
-        mu, gen, q = frame_quality(processor, gt_thw, frames, metric)
-        mus.append(mu)
-        per_round.append(q.copy())
+        worst, gen = scorer.score(processor, frames, keep_gen=policy == "qnet_mask")
+        scored += 1
         if policy == "oracle_mask":
-            sel = int(np.argmin(q))
+            sel = worst
         elif policy == "rand_mask":
             sel = rng.choice(sorted(set(range(T)) - set(frames)))
         elif policy == "qnet_mask":
@@ -108,8 +111,11 @@ def run_policy(policy: str, processor, sample, rounds: int, metric: str = "j_and
             sel = qnet_frame_selection(qnet, images, gen.float(), frames)
         else:
             sel = _upper_bound_frame(processor, gt, gt_thw, frames, metric)
-        times.append(SKIP_SECONDS if q[sel] == NO_OBJECT else MASK_SECONDS)
+        times.append(SKIP_SECONDS if empty[sel] else MASK_SECONDS)
         frames.append(sel)
+    q = scorer.qualities()
+    per_round = [q[i].copy() for i in range(scored)]
+    mus = [float(np.mean(row[~empty])) if (~empty).any() else float("nan") for row in per_round]
     return dict(mu_metrics=mus, annotation_times=times[:-1], frames=frames, round_metrics=per_round, propagated_frames=propagated)
 
 

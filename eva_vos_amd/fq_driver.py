@@ -236,27 +236,31 @@ def per_frame_j(processor, gt_dev: torch.Tensor, interacted: List[int]) -> tuple
 
 def oracle_rounds(processor, sample, rounds: int = 8, stats: dict = None):
     """The oracle annotation policy of the FQ dataset (interactions/mask.py:113-156).  `stats` (optional dict, one per caller thread):
-    the frames the engine really visited (`propagated_frames`) and the `interactions` are added to it."""
+    the frames the engine really visited (`propagated_frames`) and the `interactions` are added to it.
+    Round 6: the evaluation of a round stays on the device (metrics.RoundScorer: compose + J counts + fp64 quality + arg-min in one enqueue);
+    one int per round crosses PCIe, the per-frame J rows of all rounds are fetched once at the end.  Same values, same selection as
+    per_frame_j + numpy.argmin (tests/test_gpu_driver_golden.py)."""
     T = sample["num_frames"]
     gt = sample["gt"][0].to(processor.prob.device)              # [T,1,H,W]
-    gt_thw = gt[:, 0]
-    frames, quality, states, gens = [0], None, [], []
+    scorer = metrics.RoundScorer(gt[:, 0], "j", max_rounds=max(rounds, 1), no_object=NO_OBJECT)
+    valid = set(np.where(~scorer.empty_host)[0].tolist())       # frames that can be annotated at all (the others carry the NO_OBJECT token)
+    frames, sels, gens = [0], [], []
     for r in range(1, rounds + 1):
         if r >= T:
             continue
-        if quality is not None and not (set(range(T)) - set(np.where(quality == NO_OBJECT)[0].tolist()) - set(frames)):
+        if sels and not (valid - set(frames)):                  # not_avail_frames (interactions/eval.py:84-89): nothing left to annotate
             continue
         f = frames[r - 1]
         processor.interact(gt[f][None], f, download=False)         # [1,1,H,W] mask of the annotated frame
         if stats is not None:
             stats["propagated_frames"] = stats.get("propagated_frames", 0) + processor.stats()["frames"]
             stats["interactions"] = stats.get("interactions", 0) + 1
-        quality, gen = per_frame_j(processor, gt_thw, frames[:r])
-        worst = int(np.argmin(quality))
+        worst, gen = scorer.score(processor, frames[:r])
         frames.append(worst)
-        states.append((worst, quality.copy()))
+        sels.append(worst)
         gens.append(gen)
-    return states, gens
+    q = scorer.qualities()
+    return [(w, q[i]) for i, w in enumerate(sels)], gens
 
 
 # ------------------------------------------------------------------------------------------------ output
@@ -286,11 +290,24 @@ def write_png(path: str, a: np.ndarray, level: int = 1) -> None:
 def save_state_masks(gen: torch.Tensor, out_dir: str, pool=None):
     """224x224 nearest-neighbour PNGs like util/fq_dataset.py:64-84 (mask_to_224).  The resize runs on the device; with
     `pool` (a ThreadPoolExecutor) the PNG encoding + file writes of the state happen on host threads while the GPU
-    propagates the next round (zlib and file I/O release the GIL); returns the future, or None when done inline."""
+    propagates the next round (zlib and file I/O release the GIL); returns the future, or None when done inline.
+    Round 6: with a pool the download does not stop the lane either - the 224x224 frames go to pinned memory asynchronously and the
+    WRITER thread waits for the copy (an event), not the thread that drives the GPU."""
     small = torch.nn.functional.interpolate(gen[:, None].float(), size=(224, 224), mode="nearest")[:, 0]
-    frames = (small * 255).to(torch.uint8).cpu().numpy()
+    small = (small * 255).to(torch.uint8)
+    if pool is None or not small.is_cuda:
+        frames, ready = small.cpu().numpy(), None
+    else:
+        host = torch.empty(small.shape, dtype=torch.uint8, pin_memory=True)
+        host.copy_(small, non_blocking=True)
+        ready = torch.cuda.Event(blocking=True)
+        ready.record()
+        small.record_stream(torch.cuda.current_stream())
+        frames = host.numpy()
 
     def write():
+        if ready is not None:
+            ready.synchronize()
         os.makedirs(out_dir, exist_ok=True)
         for t, m in enumerate(frames):
             write_png(os.path.join(out_dir, f"{t:05d}.png"), m)

@@ -228,6 +228,7 @@ class InferenceCore:
         self._finalizer = weakref.finalize(self, _lib.lib().stcn_engine_destroy, h_)
         self.interacted = set()
         self.last_enqueue_s = 0.0
+        self._dl_event = None                                      # blocking event of the mask download (created on first use)
         self._pinned_live = []                                     # weak references to this core's pinned result blocks still held by arrays
 
     # ------------------------------------------------------------------------------------------
@@ -264,7 +265,12 @@ class InferenceCore:
                 # array is still a fresh one per call (it owns its pinned block - at most _PINNED_MAX_LIVE of them are alive at a time,
                 # see _pinned_result), the host waits on this stream only
                 host.copy_(out, non_blocking=True)
-                torch.cuda.current_stream().synchronize()
+                # a BLOCKING event wait: the thread sleeps until the copy has landed (hipEventBlockingSync) instead of spinning a host core in
+                # hipStreamSynchronize for the whole propagation - with 8 ranks x 4 lanes on one host the spinning lanes starve the decoders
+                if self._dl_event is None:
+                    self._dl_event = torch.cuda.Event(blocking=True)
+                self._dl_event.record()
+                self._dl_event.synchronize()
                 self.np_masks = np.asarray(block)
             else:
                 if not _PINNED_DOWNLOAD:
@@ -342,14 +348,14 @@ class InferenceCore:
     def __deepcopy__(self, memo):
         new = object.__new__(InferenceCore)
         for k, v in self.__dict__.items():
-            if k in ("_engine", "_finalizer", "prob", "masks", "np_masks", "interacted", "_pinned_live"):
+            if k in ("_engine", "_finalizer", "prob", "masks", "np_masks", "interacted", "_pinned_live", "_dl_event"):
                 continue
             new.__dict__[k] = v                                   # nets, model handle, images: shared (read-only)
         with torch.cuda.device(self.device):
             self._leave_engine_stream(torch.cuda.current_stream())     # the clones below read what the engine stream wrote
             torch.cuda.current_stream().synchronize()
             new.prob, new.masks = self.prob.clone(), self.masks.clone()
-            new.np_masks, new.interacted, new._pinned_live = self.np_masks.copy(), set(self.interacted), []
+            new.np_masks, new.interacted, new._pinned_live, new._dl_event = self.np_masks.copy(), set(self.interacted), [], None
             new._stream = torch.cuda.current_stream()
             h_ = C.c_void_p()
             _lib.check(_lib.lib().stcn_engine_clone(self._engine, new.prob.data_ptr(), new.masks.data_ptr(),

@@ -111,3 +111,66 @@ def sequence_scores_gpu(gt, pred, j_only: bool = False):
                    "stcn_metrics_jf_counts")
         c = counts.cpu().numpy()
     return _scores_from_counts(c)
+
+
+class RoundScorer:
+    """The per-round evaluation of an annotation session, kept on the device (``stcn_metrics_round``): after every ``interact()`` the
+    reference's loops compute per-frame J or J&F of the propagated masks against the ground truth (annotated frames counting with their
+    ground truth, the NO_OBJECT token for frames without the object: interactions/eval.py:27-81) and the oracle policy takes the arg-min
+    (interactions/mask.py:130-133).  Here one C call enqueues compose + counts + fp64 quality + arg-min on the engine's stream; only the
+    selected frame (4 bytes) crosses PCIe per round - the host waits for it on a BLOCKING event (it sleeps instead of spinning a core) -
+    and the quality rows of all rounds are fetched together at the end of the session (``qualities()``).  Bit-identical to the host path
+    (``sequence_scores_gpu`` + NumPy), which the tests assert."""
+
+    def __init__(self, gt_thw, metric: str = "j", max_rounds: int = 64, no_object: float = 20.0):
+        import torch
+        assert gt_thw.is_cuda and gt_thw.dim() == 3
+        self.metric, self.no_object = metric, float(no_object)
+        self.dev = gt_thw.device
+        self.gt = (gt_thw > 0.5 if gt_thw.is_floating_point() else gt_thw != 0).to(torch.uint8).contiguous()
+        self.T, self.H, self.W = (int(v) for v in self.gt.shape)
+        empty = self.gt.flatten(1).sum(1) == 0
+        self.noobj = empty.to(torch.uint8).contiguous()
+        self.empty_host = empty.cpu().numpy()                         # ONE sync per sample: which frames carry the NO_OBJECT token
+        self.annotated = torch.zeros(self.T, dtype=torch.uint8, device=self.dev)
+        self.flags_host = torch.zeros(self.T, dtype=torch.uint8).pin_memory()
+        self.counts = torch.empty((self.T, 6), dtype=torch.int32, device=self.dev)
+        self.scratch = None if metric == "j" else torch.empty((self.T * self.H * self.W,), dtype=torch.uint8, device=self.dev)
+        self.quality = torch.empty((max_rounds, self.T), dtype=torch.float64, device=self.dev)
+        self.select = torch.empty((max_rounds,), dtype=torch.int32, device=self.dev)
+        self.select_host = torch.empty((max_rounds,), dtype=torch.int32).pin_memory()
+        self.event = torch.cuda.Event(blocking=True)
+        self.rounds = 0
+
+    def score(self, processor, annotated_frames, keep_gen: bool = True):
+        """Enqueue the evaluation of the round just propagated by ``processor`` and return (selected frame, gen): gen = uint8 [T,H,W] on the
+        device (the evaluated masks; a fresh tensor when keep_gen, else a scratch that the next round overwrites)."""
+        import ctypes as C
+
+        import torch
+
+        from . import _lib
+        r = self.rounds
+        if r >= self.quality.shape[0]:
+            raise RuntimeError("RoundScorer: more rounds than max_rounds")
+        lw, uw, lh, uh = processor.pad
+        with torch.cuda.device(self.dev):
+            self.flags_host.zero_()                                   # (the previous round's copy is done: every round ends in a wait)
+            self.flags_host[sorted(set(int(f) for f in annotated_frames))] = 1
+            self.annotated.copy_(self.flags_host, non_blocking=True)  # T bytes H2D from pinned memory
+            gen = torch.empty((self.T, self.H, self.W), dtype=torch.uint8, device=self.dev) if keep_gen or not hasattr(self, "_gen") else self._gen
+            self._gen = gen
+            p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None      # noqa: E731
+            _lib.check(_lib.lib().stcn_metrics_round(
+                C.c_void_p(torch.cuda.current_stream().cuda_stream), p(processor.masks), processor.nh, processor.nw, lh, lw, p(self.gt),
+                p(self.annotated), p(self.noobj), self.T, self.H, self.W, 1 if self.metric == "j" else 0, self.no_object, p(gen), p(self.scratch),
+                p(self.counts), p(self.quality[r]), p(self.select[r:r + 1])), "stcn_metrics_round")
+            self.select_host[r:r + 1].copy_(self.select[r:r + 1], non_blocking=True)
+            self.event.record()
+            self.event.synchronize()                                  # blocking wait: the lane's host thread sleeps until the round is done
+        self.rounds = r + 1
+        return int(self.select_host[r]), gen
+
+    def qualities(self):
+        """float64 [rounds, T]: the per-frame quality of every round scored so far (one D2H copy)."""
+        return self.quality[: self.rounds].cpu().numpy()

@@ -250,6 +250,19 @@ int stcn_metrics_jf_counts(void *stream, const uint8_t *gt_dev, const uint8_t *p
  * What the oracle annotation policy needs per round (interactions/mask.py:113-146 selects the frame with the worst J; eval_processor_metric
  * with metric='j', interactions/eval.py:27-81). */
 int stcn_metrics_j_counts(void *stream, const uint8_t *gt_dev, const uint8_t *pred_dev, int T, int H, int W, int32_t *counts_dev);
+/* One annotation round scored ON THE DEVICE (enqueue only): what the reference's loops do on the host after every interact() -
+ * eval_processor_metric (interactions/eval.py:27-81: annotated frames count with their ground truth :57-60, per-frame J or J&F :62-79, the
+ * NO_OBJECT token for frames without the object :67) followed by the oracle policy's arg-min (interactions/mask.py:130-133; policies.py:62-72).
+ *   masks_dev     : the engine's uint8 [T][nh][nw] mask tensor (InferenceCore.masks), cropped at (lh, lw) to H x W
+ *   gt_dev        : uint8 [T,H,W] ground truth, non-zero = object;  annotated_dev / noobj_dev : uint8 [T] flags
+ *   gen_dev       : uint8 [T,H,W] OUT - the evaluated masks (engine mask, GT on annotated frames): the state util/fq_dataset.py:64-84 saves
+ *   scratch_dev   : uint8 [T*H*W] (unused when j_only);  counts_dev : int32 [T,6] OUT as stcn_metrics_jf_counts
+ *   quality_dev   : double [T] OUT - per-frame J (j_only) or J&F, no_object for flagged frames; fp64 with the host path's operations in the
+ *                   host path's order, i.e. bit-identical to it;  select_dev : int32 [1] OUT - first index of the minimum (numpy.argmin)
+ * Only select (4 bytes) has to cross PCIe per round; the quality rows of a session can be fetched together at its end. */
+int stcn_metrics_round(void *stream, const uint8_t *masks_dev, int nh, int nw, int lh, int lw, const uint8_t *gt_dev, const uint8_t *annotated_dev,
+                       const uint8_t *noobj_dev, int T, int H, int W, int j_only, double no_object, uint8_t *gen_dev, uint8_t *scratch_dev,
+                       int32_t *counts_dev, double *quality_dev, int32_t *select_dev);
 
 #ifdef __cplusplus
 }

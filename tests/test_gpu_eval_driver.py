@@ -82,3 +82,46 @@ def test_qnet_selection_on_device_equals_the_host_loop():
     feats = net.extract_features(imgs, m3)
     for inter in ([0], [0, 4], [2, 3, 8]):
         assert Q.qnet_frame_selection(net, frames, masks, inter) == PO.farthest_frame(feats.cpu().numpy(), inter)
+
+
+@pytest.mark.parametrize("metric,H,W", [("j", 120, 200), ("j_and_f", 120, 200), ("j_and_f", 101, 77)])
+def test_round_scorer_on_the_device_equals_the_host_path_bit_for_bit(metric, H, W):
+    """metrics.RoundScorer (stcn_metrics_round: compose + counts + fp64 quality + arg-min in one enqueue, one int per round over PCIe) against
+    what the drivers did on the host until round 5 - eval_driver.frame_quality (sequence_scores_gpu + NumPy) and numpy.argmin: the per-frame
+    values must be EQUAL as float64 bit patterns (same operations in the same order), the selection and the evaluated masks identical -
+    with annotated frames, frames without the object, an all-empty prediction, ties (several annotated frames share J = 1) and a padded
+    engine tensor (the scorer crops the engine's [T][nh][nw] masks itself)."""
+    from eva_vos_amd import metrics
+
+    class Proc:                                    # the attributes of an InferenceCore the scorer / frame_quality read
+        pass
+    T = 11
+    rng = np.random.RandomState(H + W)
+    gt = synth.synthetic_mask(T, H, W, 1, seed=5)[0, :, 0]
+    gt[3] = 0                                                          # two frames without the object
+    gt[9] = 0
+    p = Proc()
+    lh, lw = (-H) % 16 // 2, (-W) % 16 // 2
+    p.nh, p.nw = H + (-H) % 16, W + (-W) % 16
+    p.pad = (lw, p.nw - W - lw, lh, p.nh - H - lh)
+    pred = synth.synthetic_mask(T, H, W, 1, seed=6)[0, :, 0].clone()
+    pred[5] = 0                                                        # an empty prediction on a frame that has the object
+    pred[3, :7, :9] = 1                                                # a prediction on a frame without the object
+    noise = torch.from_numpy(rng.rand(T, H, W) < 0.02)
+    pred = ((pred > 0.5) ^ noise).to(torch.uint8)
+    masks = torch.zeros((T, 1, p.nh, p.nw), dtype=torch.uint8)
+    masks[:, 0, lh:lh + H, lw:lw + W] = pred
+    masks[:, 0, :lh] = 1                                               # garbage in the padding must not matter
+    p.masks = masks.cuda()
+    gt_dev = gt.cuda()
+    sc = metrics.RoundScorer(gt_dev, metric, max_rounds=4, no_object=eval_driver.NO_OBJECT)
+    assert sc.empty_host.tolist() == [t in (3, 9) for t in range(T)]
+    for r, annotated in enumerate(([0], [0, 7], [0, 7, 7, 2], list(range(T)))):
+        sel, gen = sc.score(p, annotated)
+        mu, gen_ref, q_ref = eval_driver.frame_quality(p, gt_dev, sorted(set(annotated)), metric)
+        q = sc.qualities()[r]
+        assert q.dtype == np.float64 and np.array_equal(q.view(np.uint64), q_ref.view(np.uint64)), (r, np.abs(q - q_ref).max())
+        assert sel == int(np.argmin(q_ref)), (r, sel, int(np.argmin(q_ref)))
+        assert torch.equal(gen, gen_ref)
+        assert all(q[f] == (eval_driver.NO_OBJECT if f in (3, 9) else 1.0) for f in annotated)
+    assert sc.qualities().shape == (4, T)
