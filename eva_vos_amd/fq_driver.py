@@ -36,6 +36,24 @@ NO_OBJECT = 20.0          # the reference's token for frames without the object 
 
 
 # ------------------------------------------------------------------------------------------------ data
+_DECODE_POOL = None
+_DECODE_LOCK = __import__("threading").Lock()
+
+
+def decode_pool():
+    """The process-wide pool of image-decode threads (STCN_DECODE_THREADS, default min(16, host cores / 2); 0 = decode inline).  Shared by
+    every lane's loader: what matters is that the NEXT sample of every lane is ready when the lane asks for it, not who decodes it."""
+    global _DECODE_POOL
+    n = int(os.environ.get("STCN_DECODE_THREADS", min(16, max(1, (os.cpu_count() or 2) // 2))))
+    if n <= 0:
+        return None
+    with _DECODE_LOCK:
+        if _DECODE_POOL is None:
+            from concurrent.futures import ThreadPoolExecutor
+            _DECODE_POOL = ThreadPoolExecutor(n, thread_name_prefix="stcn-decode")
+        return _DECODE_POOL
+
+
 class ClipDataset:
     """DAVIS/MOSE directory layout: JPEGImages/480p/<video>/%05d.jpg, Annotations/480p/<video>/%05d.png
     (palette index = object id).  One sample per (video, object), named ``<video>__<obj>``."""
@@ -63,12 +81,24 @@ class ClipDataset:
 
     def _clip(self, video: str, n: int):
         """Decoded once per video (samples of a video are adjacent): the frames as uint8 [T,H,W,3] - pinned when a GPU is there, so
-        that the prefetcher can upload the BYTES (a quarter of the fp32 clip) and normalise on the device - and the label maps."""
+        that the prefetcher can upload the BYTES (a quarter of the fp32 clip) and normalise on the device - and the label maps.
+        Round 6: the frames of a video are decoded by a SHARED pool of host threads (PIL releases the GIL while it decodes): one thread
+        per lane took ~150 ms per 40-frame 480p video, more than the GPU needs for its eight rounds - the lanes waited for their loaders."""
         if video not in self._cache:
             self._cache.clear()                  # keep one decoded clip
-            u8 = np.stack([np.asarray(Image.open(os.path.join(self.image_dir, video, f"{f:05d}.jpg")).convert("RGB")) for f in range(n)])
-            lab = np.stack([np.array(Image.open(os.path.join(self.mask_dir, video, f"{f:05d}.png")).convert("P"),
-                                     dtype=np.uint8) for f in range(n)])
+
+            def frame(f):
+                return np.asarray(Image.open(os.path.join(self.image_dir, video, f"{f:05d}.jpg")).convert("RGB"))
+
+            def label(f):
+                return np.array(Image.open(os.path.join(self.mask_dir, video, f"{f:05d}.png")).convert("P"), dtype=np.uint8)
+
+            pool = decode_pool()
+            if pool is None:
+                u8, lab = np.stack([frame(f) for f in range(n)]), np.stack([label(f) for f in range(n)])
+            else:
+                fr, lb = [pool.submit(frame, f) for f in range(n)], [pool.submit(label, f) for f in range(n)]
+                u8, lab = np.stack([x.result() for x in fr]), np.stack([x.result() for x in lb])
             u8 = torch.from_numpy(np.ascontiguousarray(u8))
             if torch.cuda.is_available():
                 u8 = u8.pin_memory()
