@@ -1,7 +1,7 @@
 """GPU box: does the F(4x4) Winograd decoder cost mask parity?  BASELINE config 1 (480x854, k = 1, mem_freq = 5, T = 82,
 interact(0) then interact(41)) on the CPU oracle once, and on the HIP engine in two fresh processes: default (decoder side on
 F(4x4,3x3)) and STCN_WINO4=0 (F(2x2) / direct everywhere).  Prints the pixels differing from the oracle per arm and between the arms.
-Usage: python tools/wino4_ab_parity.py [--frames 82]"""
+Usage: python tools/wino4_ab_parity.py [--frames 82]      (AB_ENV="STCN_WINO4_KEYPROJ=1": that arm instead of STCN_WINO4=0)"""
 import os
 import subprocess
 import sys
@@ -49,7 +49,9 @@ def main():
     tmp = tempfile.mkdtemp()
     arms = {}
     arms_list = [("wino4", {}), ("no_wino4", {"STCN_WINO4": "0"})]
-    if os.environ.get("AB_LIB"):                    # a variant build as the second arm (STCN_LIB) instead of STCN_WINO4=0
+    if os.environ.get("AB_ENV"):                    # AB_ENV="NAME=VAL NAME=VAL": the second arm = the default engine under these variables
+        arms_list = [("wino4", {}), ("no_wino4", dict(kv.split("=", 1) for kv in os.environ["AB_ENV"].split()))]
+    elif os.environ.get("AB_LIB"):                    # a variant build as the second arm (STCN_LIB) instead of STCN_WINO4=0
         arms_list = [("wino4", {}), ("no_wino4", {"STCN_LIB": os.environ["AB_LIB"]})]
     for name, env in arms_list:
         out = os.path.join(tmp, name + ".npz")
