@@ -668,8 +668,9 @@ def session_leg(prop, fuse, H, W, T, rounds, metric, videos=4, lanes_list=(1, 2,
     one first interaction, then short fused spans; J or J&F per frame on the device after every round, annotated frames counting with their
     ground truth) on a fresh InferenceCore per sample, as generate_fq_dataset.py:63-70 / interactions/mask.py:24-26 build them.  Clips, ground
     truth and weights are resident before the timed region (no JPEG decode, no output files: the `drivers` leg has those).  Reported per lane
-    count: rounds/s, TRUE propagated frames/s (the engines' own visit counts) and `device_busy_frac` = kernel ms the same sessions need
-    (HIP events per launch, one profiled pass) / wall time."""
+    count: rounds/s, TRUE propagated frames/s (the engines' own visit counts) and `device_busy_frac` = the ENGINE kernel ms the same sessions
+    need when every launch runs alone (HIP events per launch, one profiled pass on one stream) / wall time: 1.0 = the wall time is the sum of
+    the solo kernel durations (above 1.0: concurrent launches filled each other's tails; the metric kernels are not in the numerator)."""
     import threading
     from eva_vos_amd import eval_driver, synth
     from mivos.inference_core import InferenceCore
@@ -698,7 +699,10 @@ def session_leg(prop, fuse, H, W, T, rounds, metric, videos=4, lanes_list=(1, 2,
         return len(res["mu_metrics"]), res["propagated_frames"], kms[0], res["frames"]
 
     def region(lanes, prof=False):
-        eo = {"lookahead": 0} if lanes > 1 else {"lookahead": 2}
+        # one lane: the engine's own side streams on; several lanes: off (they fill each other's gaps).  The profiled pass runs WITHOUT side
+        # streams: its per-launch durations are then solo durations (kernels that overlap on the chip each take longer; their sum would
+        # exceed the wall time - round 6's first capture read 1.25 that way)
+        eo = {"lookahead": 0} if lanes > 1 or prof else {"lookahead": 2}
         dev = torch.cuda.current_device()
         parts = [samples[l::lanes] for l in range(lanes)]
         acc = [[0, 0, 0.0] for _ in range(lanes)]

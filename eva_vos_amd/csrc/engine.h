@@ -177,6 +177,15 @@ struct stcn_engine {
     hipStream_t side2 = nullptr;
     stcn::Work work_side2;
     int key_rr = 0;                      // which side stream takes the next key batch
+    // round 6: the BACKWARD sweep of an interaction on its own stream and workspace, concurrently with the forward sweep (the two sweeps
+    // of do_pass share nothing but the certain memory, which neither writes: inference_core.py:250-253 runs them one after the other).
+    // Its temporary bank slots grow DOWNWARD from bank_lo, in front of the certain slots, the forward sweep's upward behind them: each
+    // sweep reads one contiguous row range [its temporaries | certain] / [certain | its temporaries].  One video in flight only (same
+    // switch as the key-encoder look-ahead); clips longer than the key cache (flush-all policy) keep the serial order.
+    hipStream_t stream2 = nullptr;
+    stcn::Work work2;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int bank_lo = 0;                     // bank slots in front of the certain slots (0: serial sweeps)
     std::vector<hipEvent_t> key_ready;   // per frame: recorded on `side` after its encode_key
     std::vector<char> key_pending;       // per frame: main stream has not yet waited on key_ready
     int lookahead = 0;

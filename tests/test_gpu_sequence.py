@@ -392,6 +392,45 @@ def test_two_key_encoder_streams_are_bit_identical_to_one_even_when_they_run_lat
         assert torch.equal(res[key][2], res[("1", 0)][2]), key
 
 
+@pytest.mark.parametrize("k", [1, 2])
+def test_the_backward_sweep_beside_the_forward_one_changes_nothing_but_the_timing(nets, nets_multi, monkeypatch, k):
+    """Round 6: with one video in flight the backward sweep of an interaction runs on a second stream + workspace BESIDE the forward sweep
+    (the sweeps share only the certain memory, read-only: inference_core.py:250-253 runs them one after the other); its temporary bank slots
+    sit in front of the certain slots.  (i) Same arithmetic whatever the timing: a late second stream (stcn_test_side_delay_us also delays
+    the backward sweep and the key-encoder streams) must reproduce the undelayed result BIT for bit - first interaction in the middle of
+    the clip (both sweeps encode keys), a fused round between two interactions, a round whose backward sweep is empty, a re-annotation.
+    (ii) Against the serial engine (STCN_DUAL_SWEEP=0) the masks agree to 1e-3 IoU and the probabilities to 2e-3: only the ORDER of the
+    bank rows a backward sweep reads differs (temporaries in front), i.e. the order of the 50-term read-out sums."""
+    from eva_vos_amd import _lib
+    nets_ = nets if k == 1 else nets_multi
+    T, H, W = 21, 112, 144
+    img, msk = synth.synthetic_clip(T, H, W, seed=24), synth.synthetic_mask(T, H, W, k, seed=25)
+    monkeypatch.setenv("STCN_LOOKAHEAD", "2")
+    script = (10, 16, 0, 13, 10)
+
+    def run(dual, delay):
+        monkeypatch.setenv("STCN_DUAL_SWEEP", dual)
+        _lib.check(_lib.lib().stcn_test_side_delay_us(delay))
+        try:
+            core = make_core(nets_)(img, k, 3)
+            outs = []
+            for idx in script:
+                m = msk[:, idx] if k == 1 else torch.cat([1 - msk[:, idx].sum(0, keepdim=True).clamp(0, 1), msk[:, idx]], 0)
+                outs.append((core.interact(m, idx, scribble=k > 1).copy(), core.prob.clone(), core.stats()))
+            return outs
+        finally:
+            _lib.check(_lib.lib().stcn_test_side_delay_us(0))
+
+    base, late, serial = run("1", 0), run("1", 400), run("0", 0)
+    for r, idx in enumerate(script):
+        assert np.array_equal(base[r][0], late[r][0]) and torch.equal(base[r][1], late[r][1]), f"round {r} (frame {idx}): the result depends on the timing of the second stream"
+        assert base[r][2] == serial[r][2], (base[r][2], serial[r][2])          # same frames, fusions, bank sizes
+        for o in range(1, k + 1):
+            assert iou(base[r][0] == o, serial[r][0] == o) >= 1 - 1e-3
+        assert (base[r][1] - serial[r][1]).abs().max().item() < 2e-3
+    assert base[1][2]["fused"] > 0 and base[0][2]["bank_bwd"] > 1 and base[0][2]["bank_fwd"] > 1
+
+
 @pytest.mark.parametrize("T,mem_freq,idx", [(30, 12, 17), (9, 50, 0), (3, 5, 1), (2, 1, 0)])
 def test_decode_groups_with_large_mem_freq_and_tiny_clips(nets, monkeypatch, T, mem_freq, idx):
     """Group formation corner cases: mem_freq above the 8-frame group cap, mem_freq beyond the clip (no insertion at
