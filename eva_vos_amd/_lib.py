@@ -63,7 +63,7 @@ PROTOTYPES = {
     "stcn_test_fusion": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _I, _I, _P]),
     "stcn_metrics_jf_counts": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
     "stcn_metrics_j_counts": (_I, [_P, _P, _P, _I, _I, _I, _P]),
-    "stcn_metrics_round": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _D, _P, _P, _P, _P, _P]),
+    "stcn_metrics_round": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _D, _P, _P, _P, _P, _P]),
     "stcn_bench_conv": (_I, [_P] + [_I] * 11 + [C.POINTER(_F), C.POINTER(_D)]),
     "stcn_bench_mfma_rate": (_I, [_P, _I, C.POINTER(_F), C.POINTER(_F)]),
     "stcn_pool_release": (_I, []),

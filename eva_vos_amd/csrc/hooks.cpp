@@ -307,16 +307,18 @@ int stcn_metrics_j_counts(void *stream, const uint8_t *gt_dev, const uint8_t *pr
 }
 
 int stcn_metrics_round(void *stream, const uint8_t *masks_dev, int nh, int nw, int lh, int lw, const uint8_t *gt_dev, const uint8_t *annotated_dev,
-                       const uint8_t *noobj_dev, int T, int H, int W, int j_only, double no_object, uint8_t *gen_dev, uint8_t *scratch_dev,
+                       const uint8_t *noobj_dev, int T, int H, int W, int t0, int t1, int j_only, double no_object, uint8_t *gen_dev, uint8_t *scratch_dev,
                        int32_t *counts_dev, double *quality_dev, int32_t *select_dev) {
     if (!masks_dev || !gt_dev || !annotated_dev || !noobj_dev || !gen_dev || !counts_dev || !quality_dev || !select_dev || (!j_only && !scratch_dev) ||
-        T < 1 || H < 2 || W < 2 || lh < 0 || lw < 0 || lh + H > nh || lw + W > nw) {
+        T < 1 || H < 2 || W < 2 || lh < 0 || lw < 0 || lh + H > nh || lw + W > nw || t0 < 0 || t1 > T || t0 >= t1) {
         set_error("stcn_metrics_round: bad arguments");
         return STCN_E_INVALID;
     }
     const int radius = j_only ? -1 : (int)std::ceil(0.008 * std::sqrt((double)H * H + (double)W * W));      // interactions/metrics.py:119-120
-    round_score_launch(masks_dev, nh, nw, lh, lw, gt_dev, annotated_dev, noobj_dev, T, H, W, radius, no_object, gen_dev, scratch_dev, counts_dev,
-                       quality_dev, select_dev, (hipStream_t)stream);
+    // frames [t0, t1): composed and counted now; the counts (and gen) of the other frames are the caller's from earlier rounds
+    const size_t hw = (size_t)H * W;
+    round_score_launch(masks_dev + (size_t)t0 * nh * nw, nh, nw, lh, lw, gt_dev + t0 * hw, annotated_dev + t0, noobj_dev, t1 - t0, H, W, radius, no_object,
+                       gen_dev + t0 * hw, scratch_dev, counts_dev + (size_t)t0 * 6, T, quality_dev, select_dev, (hipStream_t)stream, t0);
     HIPCHK(hipGetLastError());
     return STCN_OK;
 }

@@ -208,9 +208,10 @@ void pack_fusion_input_launch(const float *img4, const float *prev, const float 
 void jf_counts_launch(const uint8_t *gt, const uint8_t *pred, int T, int H, int W, int radius, uint8_t *bmap,
                       int *counts, hipStream_t s);
 // one annotation round scored on the device: gen = engine mask / GT on annotated frames, J or J&F counts, fp64 quality per frame, arg-min
+// (pointers at the first of the Tn frames to recount; quality / arg-min over the T_all frames of the clip, t0 = index of that first frame)
 void round_score_launch(const uint8_t *masks, int nh, int nw, int lh, int lw, const uint8_t *gt, const uint8_t *annotated, const uint8_t *noobj,
-                        int T, int H, int W, int radius, double no_object, uint8_t *gen, uint8_t *bmap, int *counts, double *quality, int *select,
-                        hipStream_t s);
+                        int Tn, int H, int W, int radius, double no_object, uint8_t *gen, uint8_t *bmap, int *counts, int T_all, double *quality,
+                        int *select, hipStream_t s, int t0);
 
 // debug/stress: launch ONLY the merge stage on prepared candidate lists (cand_v/cand_i [NC][Q][50])
 void merge_only_launch(const float *cand_v, const int32_t *cand_i, int NC, int Q, const float *mv, long mv_os, int k,

@@ -184,14 +184,17 @@ __global__ __launch_bounds__(256) void round_quality_kernel(const int *__restric
     if (threadIdx.x == 0) select[0] = si[0];
 }
 
+// masks / gt / annotated / gen / counts point at the FIRST of the Tn frames to (re)compose and count; the quality and the arg-min cover all
+// T_all frames of the clip, whose counts start Tn0 = (counts - counts_all) / 6 frames earlier: the caller passes counts of frame t0 and T_all,
+// noobj and quality are whole-clip arrays
 void round_score_launch(const uint8_t *masks, int nh, int nw, int lh, int lw, const uint8_t *gt, const uint8_t *annotated, const uint8_t *noobj,
-                        int T, int H, int W, int radius, double no_object, uint8_t *gen, uint8_t *bmap, int *counts, double *quality, int *select,
-                        hipStream_t s) {
-    const long n = (long)T * H * W;
+                        int Tn, int H, int W, int radius, double no_object, uint8_t *gen, uint8_t *bmap, int *counts, int T_all, double *quality,
+                        int *select, hipStream_t s, int t0) {
+    const long n = (long)Tn * H * W;
     const unsigned blocks = (unsigned)std::min<long>((n + 255) / 256, 4096);
-    hipLaunchKernelGGL(round_compose_kernel, dim3(blocks), dim3(256), 0, s, masks, nh, nw, lh, lw, gt, annotated, T, H, W, gen);
-    jf_counts_launch(gt, gen, T, H, W, radius, bmap, counts, s);
-    hipLaunchKernelGGL(round_quality_kernel, dim3(1), dim3(256), 0, s, counts, noobj, T, radius < 0 ? 1 : 0, no_object, quality, select);
+    hipLaunchKernelGGL(round_compose_kernel, dim3(blocks), dim3(256), 0, s, masks, nh, nw, lh, lw, gt, annotated, Tn, H, W, gen);
+    jf_counts_launch(gt, gen, Tn, H, W, radius, bmap, counts, s);
+    hipLaunchKernelGGL(round_quality_kernel, dim3(1), dim3(256), 0, s, counts - (long)t0 * 6, noobj, T_all, radius < 0 ? 1 : 0, no_object, quality, select);
 }
 
 void jf_counts_launch(const uint8_t *gt, const uint8_t *pred, int T, int H, int W, int radius, uint8_t *bmap,

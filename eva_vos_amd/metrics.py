@@ -142,9 +142,12 @@ class RoundScorer:
         self.event = torch.cuda.Event(blocking=True)
         self.rounds = 0
 
-    def score(self, processor, annotated_frames, keep_gen: bool = True):
+    def score(self, processor, annotated_frames, keep_gen: bool = True, incremental: bool = True):
         """Enqueue the evaluation of the round just propagated by ``processor`` and return (selected frame, gen): gen = uint8 [T,H,W] on the
-        device (the evaluated masks; a fresh tensor when keep_gen, else a scratch that the next round overwrites)."""
+        device (the evaluated masks; a fresh tensor when keep_gen, else a scratch that the next round overwrites).  ``annotated_frames``:
+        every frame annotated so far, the one annotated in THIS round last.  ``incremental``: from the second round on only the frames the
+        round can have changed - between the neighbouring annotated frames of the new one - are composed and counted again (the masks of the
+        others are what they were: the engine only rewrites the probabilities of the frames it visits)."""
         import ctypes as C
 
         import torch
@@ -154,17 +157,30 @@ class RoundScorer:
         if r >= self.quality.shape[0]:
             raise RuntimeError("RoundScorer: more rounds than max_rounds")
         lw, uw, lh, uh = processor.pad
+        frames = [int(f) for f in annotated_frames]
+        cur, others = frames[-1], set(frames[:-1]) - {frames[-1]}
+        t0, t1 = 0, self.T
+        if incremental and r > 0:
+            t0 = max([f for f in others if f < cur] + [-1]) + 1
+            t1 = min([f for f in others if f > cur] + [self.T])
         with torch.cuda.device(self.dev):
             self.flags_host.zero_()                                   # (the previous round's copy is done: every round ends in a wait)
-            self.flags_host[sorted(set(int(f) for f in annotated_frames))] = 1
+            self.flags_host[sorted(set(frames))] = 1
             self.annotated.copy_(self.flags_host, non_blocking=True)  # T bytes H2D from pinned memory
-            gen = torch.empty((self.T, self.H, self.W), dtype=torch.uint8, device=self.dev) if keep_gen or not hasattr(self, "_gen") else self._gen
+            prev = getattr(self, "_gen", None)
+            if prev is None:
+                gen = torch.empty((self.T, self.H, self.W), dtype=torch.uint8, device=self.dev)
+                t0, t1 = 0, self.T
+            elif keep_gen:
+                gen = prev.clone() if (t0, t1) != (0, self.T) else torch.empty_like(prev)      # the frames outside [t0, t1) carry over
+            else:
+                gen = prev
             self._gen = gen
             p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None      # noqa: E731
             _lib.check(_lib.lib().stcn_metrics_round(
                 C.c_void_p(torch.cuda.current_stream().cuda_stream), p(processor.masks), processor.nh, processor.nw, lh, lw, p(self.gt),
-                p(self.annotated), p(self.noobj), self.T, self.H, self.W, 1 if self.metric == "j" else 0, self.no_object, p(gen), p(self.scratch),
-                p(self.counts), p(self.quality[r]), p(self.select[r:r + 1])), "stcn_metrics_round")
+                p(self.annotated), p(self.noobj), self.T, self.H, self.W, t0, t1, 1 if self.metric == "j" else 0, self.no_object, p(gen),
+                p(self.scratch), p(self.counts), p(self.quality[r]), p(self.select[r:r + 1])), "stcn_metrics_round")
             self.select_host[r:r + 1].copy_(self.select[r:r + 1], non_blocking=True)
             self.event.record()
             self.event.synchronize()                                  # blocking wait: the lane's host thread sleeps until the round is done

@@ -259,9 +259,12 @@ int stcn_metrics_j_counts(void *stream, const uint8_t *gt_dev, const uint8_t *pr
  *   scratch_dev   : uint8 [T*H*W] (unused when j_only);  counts_dev : int32 [T,6] OUT as stcn_metrics_jf_counts
  *   quality_dev   : double [T] OUT - per-frame J (j_only) or J&F, no_object for flagged frames; fp64 with the host path's operations in the
  *                   host path's order, i.e. bit-identical to it;  select_dev : int32 [1] OUT - first index of the minimum (numpy.argmin)
- * Only select (4 bytes) has to cross PCIe per round; the quality rows of a session can be fetched together at its end. */
+ * Only select (4 bytes) has to cross PCIe per round; the quality rows of a session can be fetched together at its end.
+ * [t0, t1): the frames whose masks the round just propagated can have changed (the spans on both sides of the new annotation, and the annotated
+ *   frame itself): only they are composed and counted; gen / counts of the other frames are kept from the caller's earlier rounds (the first
+ *   round passes 0, T).  quality / select always cover all T frames. */
 int stcn_metrics_round(void *stream, const uint8_t *masks_dev, int nh, int nw, int lh, int lw, const uint8_t *gt_dev, const uint8_t *annotated_dev,
-                       const uint8_t *noobj_dev, int T, int H, int W, int j_only, double no_object, uint8_t *gen_dev, uint8_t *scratch_dev,
+                       const uint8_t *noobj_dev, int T, int H, int W, int t0, int t1, int j_only, double no_object, uint8_t *gen_dev, uint8_t *scratch_dev,
                        int32_t *counts_dev, double *quality_dev, int32_t *select_dev);
 
 #ifdef __cplusplus

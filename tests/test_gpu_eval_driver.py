@@ -114,14 +114,23 @@ def test_round_scorer_on_the_device_equals_the_host_path_bit_for_bit(metric, H, 
     masks[:, 0, :lh] = 1                                               # garbage in the padding must not matter
     p.masks = masks.cuda()
     gt_dev = gt.cuda()
-    sc = metrics.RoundScorer(gt_dev, metric, max_rounds=4, no_object=eval_driver.NO_OBJECT)
+    sc = metrics.RoundScorer(gt_dev, metric, max_rounds=5, no_object=eval_driver.NO_OBJECT)
     assert sc.empty_host.tolist() == [t in (3, 9) for t in range(T)]
-    for r, annotated in enumerate(([0], [0, 7], [0, 7, 7, 2], list(range(T)))):
-        sel, gen = sc.score(p, annotated)
+    # one new annotation per round, the last of the list (7 twice: a re-annotation); like the engine, a round only rewrites the masks of the
+    # frames between the neighbouring annotated frames of the new one - the scorer recounts exactly those (incremental) - and the last
+    # round flags every frame at once and is scored in full
+    script = ([0], [0, 7], [0, 7, 2], [0, 2, 7, 7], list(range(T)))
+    for r, annotated in enumerate(script):
+        if 0 < r < 4:
+            cur, others = annotated[-1], set(annotated[:-1]) - {annotated[-1]}
+            lo, hi = max([f for f in others if f < cur] + [-1]), min([f for f in others if f > cur] + [T])
+            flip = torch.from_numpy(rng.rand(hi - lo - 1, H, W) < 0.01).to(torch.uint8).cuda()
+            p.masks[lo + 1:hi, 0, lh:lh + H, lw:lw + W] ^= flip           # what a propagation round may change
+        sel, gen = sc.score(p, annotated, incremental=r < 4)
         mu, gen_ref, q_ref = eval_driver.frame_quality(p, gt_dev, sorted(set(annotated)), metric)
         q = sc.qualities()[r]
         assert q.dtype == np.float64 and np.array_equal(q.view(np.uint64), q_ref.view(np.uint64)), (r, np.abs(q - q_ref).max())
         assert sel == int(np.argmin(q_ref)), (r, sel, int(np.argmin(q_ref)))
-        assert torch.equal(gen, gen_ref)
+        assert torch.equal(gen, gen_ref), r
         assert all(q[f] == (eval_driver.NO_OBJECT if f in (3, 9) else 1.0) for f in annotated)
-    assert sc.qualities().shape == (4, T)
+    assert sc.qualities().shape == (5, T)
