@@ -172,11 +172,6 @@ struct stcn_engine {
     // key-encoder look-ahead: frames ahead of the decode chain are encoded on a side stream
     hipStream_t side = nullptr;
     stcn::Work work_side;
-    // round 6: a SECOND key-encoder stream (own workspace): consecutive key batches alternate between the two, so two encoder passes and the
-    // decode chain are in flight together - one video then fills the chip's kernel tails the way several lanes do (STCN_KEY_STREAMS=1: off)
-    hipStream_t side2 = nullptr;
-    stcn::Work work_side2;
-    int key_rr = 0;                      // which side stream takes the next key batch
     // round 6: the BACKWARD sweep of an interaction on its own stream and workspace, concurrently with the forward sweep (the two sweeps
     // of do_pass share nothing but the certain memory, which neither writes: inference_core.py:250-253 runs them one after the other).
     // Its temporary bank slots grow DOWNWARD from bank_lo, in front of the certain slots, the forward sweep's upward behind them: each

@@ -25,6 +25,7 @@ import copy
 import csv
 import os
 import random
+import time
 from typing import List
 
 import numpy as np
@@ -137,10 +138,14 @@ def run(root: str, imset: str, out_csv: str, prop_net, fuse_net, policy: str = "
 
     def work(i, sample):
         rows = []
+        t_c = time.perf_counter()
         proc = InferenceCore(prop_net, fuse_net, sample["rgb"], 1, engine_options=lane_engine_options(lanes))
+        t_s = time.perf_counter()
         res = run_policy(policy, proc, sample, rounds, metric, qnet, random.Random(seed * 100003 + i))
         if stats is not None:
             with stats_lock:
+                stats["create_s"] = stats.get("create_s", 0.0) + t_s - t_c
+                stats["session_s"] = stats.get("session_s", 0.0) + time.perf_counter() - t_s
                 stats["propagated_frames"] = stats.get("propagated_frames", 0) + res["propagated_frames"]
                 stats["interactions"] = stats.get("interactions", 0) + len(res["mu_metrics"])
         for r, (mu, sec, q) in enumerate(zip(res["mu_metrics"], res["annotation_times"], res["round_metrics"])):
@@ -150,7 +155,7 @@ def run(root: str, imset: str, out_csv: str, prop_net, fuse_net, policy: str = "
             rows.append(row)
         return rows
 
-    rows = run_lanes(root, imset, mine, lanes, work, device)
+    rows = run_lanes(root, imset, mine, lanes, work, device, stats)
     allrows = shard.gather_rows(np.stack(rows) if rows else np.zeros((0, width), np.float32), width)
     if rank == 0 and out_csv:
         os.makedirs(os.path.dirname(os.path.abspath(out_csv)), exist_ok=True)

@@ -22,6 +22,7 @@ from __future__ import annotations
 import argparse
 import csv
 import os
+import time
 from typing import Dict, List
 
 import numpy as np
@@ -148,7 +149,7 @@ class ClipDataset:
         return sample
 
 
-def prefetched(ds: "ClipDataset", indices, device: str = "cuda"):
+def prefetched(ds: "ClipDataset", indices, device: str = "cuda", timing: dict = None):
     """Yield (i, sample) for i in indices with sample['rgb'] already on `device`.  The NEXT sample is decoded on a
     host thread (PIL releases the GIL) into pinned memory as BYTES, copied H2D and normalised on a side stream while the caller
     propagates the current one (round 4: the host used to normalise in four NumPy passes over 200 MB per clip and upload fp32) - the reference decodes and uploads synchronously between samples (generate_fq_dataset.py:60-63)."""
@@ -172,13 +173,19 @@ def prefetched(ds: "ClipDataset", indices, device: str = "cuda"):
     with ThreadPoolExecutor(1) as pool:
         fut = pool.submit(load, indices[0]) if indices else None
         for n, i in enumerate(indices):
+            t_w = time.perf_counter()
             sample = fut.result()
+            if timing is not None:                                # how long the lane stood waiting for its loader (decode + upload not hidden)
+                timing["wait_input_s"] = timing.get("wait_input_s", 0.0) + time.perf_counter() - t_w
             fut = pool.submit(load, indices[n + 1]) if n + 1 < len(indices) else None
             if on_gpu:
                 torch.cuda.current_stream().wait_event(sample.pop("_ready"))
                 sample["rgb"].record_stream(torch.cuda.current_stream())
                 sample.pop("_host")
             yield i, sample
+
+
+_STATS_LOCK = __import__("threading").Lock()
 
 
 def lane_engine_options(lanes: int):
@@ -189,7 +196,7 @@ def lane_engine_options(lanes: int):
     return {"lookahead": 0} if lanes > 1 and "STCN_LOOKAHEAD" not in os.environ else None
 
 
-def run_lanes(root: str, imset: str, mine, lanes: int, work, device: str = "cuda"):
+def run_lanes(root: str, imset: str, mine, lanes: int, work, device: str = "cuda", stats: dict = None):
     """Process the samples `mine` on `lanes` host threads, each with its own HIP stream, clip loader and prefetcher
     (samples are independent; two videos in flight fill each other's kernel tails, as bench.py's lanes do).
     work(i, sample) -> list of rows; returns all rows.  Chunks are contiguous so that the objects of one video stay
@@ -210,11 +217,20 @@ def run_lanes(root: str, imset: str, mine, lanes: int, work, device: str = "cuda
         else:
             import contextlib
             ctx = contextlib.nullcontext()
+        timing = {} if stats is not None else None
+        t_lane = time.perf_counter()
         with ctx:
-            for i, sample in prefetched(ds, mine[bounds[l]:bounds[l + 1]], device):
+            for i, sample in prefetched(ds, mine[bounds[l]:bounds[l + 1]], device, timing):
+                t_s = time.perf_counter()
                 rows += work(i, sample)
+                if timing is not None:
+                    timing["work_s"] = timing.get("work_s", 0.0) + time.perf_counter() - t_s
             if on_gpu:
                 torch.cuda.current_stream().synchronize()
+        if stats is not None:                                      # host-side account of the lane: where its wall time went
+            timing["lane_s"] = time.perf_counter() - t_lane
+            with _STATS_LOCK:
+                stats.setdefault("lanes", []).append({k_: round(v_, 4) for k_, v_ in timing.items()})
         return rows
 
     if lanes == 1:
@@ -398,10 +414,13 @@ def run(root: str, imset: str, out: str, prop_net, fuse_net, rounds: int = 8, sa
                 saved_rgb.add(sample["video"])
             if first:
                 pending.append(save_rgb_frames(sample["rgb"][0], os.path.join(out, "RGBFrames", "224", sample["video"]), writers))
+        t_c = time.perf_counter()
         proc = InferenceCore(prop_net, fuse_net, sample["rgb"], 1, engine_options=lane_engine_options(lanes))
-        mine_stats = {} if stats is not None else None
+        mine_stats = {"create_s": time.perf_counter() - t_c} if stats is not None else None
+        t_c = time.perf_counter()
         states, gens = oracle_rounds(proc, sample, rounds, mine_stats)
         if stats is not None:
+            mine_stats["session_s"] = time.perf_counter() - t_c
             with rgb_lock:
                 for k_, v_ in mine_stats.items():
                     stats[k_] = stats.get(k_, 0) + v_
@@ -418,9 +437,12 @@ def run(root: str, imset: str, out: str, prop_net, fuse_net, rounds: int = 8, sa
             sid += 1
         return rows
 
-    rows = run_lanes(root, imset, mine, lanes, work, device)
+    rows = run_lanes(root, imset, mine, lanes, work, device, stats)
+    t_p = time.perf_counter()
     for f in pending:
         f.result()                                         # surface write errors; all PNGs are on disk before the CSV
+    if stats is not None:
+        stats["wait_writers_s"] = round(time.perf_counter() - t_p, 4)
     if writers is not None:
         writers.shutdown()
     allrows = shard.gather_rows(np.stack(rows) if rows else np.zeros((0, width), np.float32), width)

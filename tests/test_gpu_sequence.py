@@ -366,32 +366,6 @@ def test_key_batching_does_not_change_results(nets, monkeypatch, lookahead):
         assert (res[kb][2] - res["1"][2]).abs().max().item() < 2e-3
 
 
-def test_two_key_encoder_streams_are_bit_identical_to_one_even_when_they_run_late(nets, monkeypatch):
-    """Round 6: consecutive key batches alternate between TWO encoder streams (own workspaces) and the engine looks two groups ahead; the
-    decode chain picks every frame's keys up behind that frame's own event.  Same kernels on the same data in another interleaving: the
-    result must equal the one-stream engine bit for bit - forward and backward sweeps, a second (fused) round, and with the side streams
-    delayed (stcn_test_side_delay_us also delays FusionNet's stream: orderings held only by events become observable)."""
-    from eva_vos_amd import _lib
-    T, H, W = 23, 112, 144
-    img, msk = synth.synthetic_clip(T, H, W, seed=14), synth.synthetic_mask(T, H, W, 1, seed=15)
-    monkeypatch.setenv("STCN_LOOKAHEAD", "2")
-    res = {}
-    for ks, delay in (("1", 0), ("2", 0), ("2", 300)):
-        monkeypatch.setenv("STCN_KEY_STREAMS", ks)
-        _lib.check(_lib.lib().stcn_test_side_delay_us(delay))
-        try:
-            core = make_core(nets)(img, 1, 3)
-            m1 = core.interact(msk[:, 11], 11).copy()
-            assert core.stats()["key_miss"] == T
-            m2 = core.interact(msk[:, 3], 3).copy()
-            res[(ks, delay)] = (m1, m2, core.prob.clone())
-        finally:
-            _lib.check(_lib.lib().stcn_test_side_delay_us(0))
-    for key in (("2", 0), ("2", 300)):
-        assert np.array_equal(res[key][0], res[("1", 0)][0]) and np.array_equal(res[key][1], res[("1", 0)][1])
-        assert torch.equal(res[key][2], res[("1", 0)][2]), key
-
-
 @pytest.mark.parametrize("k", [1, 2])
 def test_the_backward_sweep_beside_the_forward_one_changes_nothing_but_the_timing(nets, nets_multi, monkeypatch, k):
     """Round 6: with one video in flight the backward sweep of an interaction runs on a second stream + workspace BESIDE the forward sweep

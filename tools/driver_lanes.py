@@ -21,11 +21,13 @@ with tempfile.TemporaryDirectory() as tmp:
     imset = fq_driver.make_synthetic_tree(os.path.join(tmp, "db"), {f"v{i}": (T, 480, 854, 1) for i in range(nv)})
     fq_driver.run(os.path.join(tmp, "db"), imset, os.path.join(tmp, "warm"), prop, fuse, rounds=2)
     for lanes in (1, 2, 3, 4):
-        for name, fn in (("fq_driver", lambda: fq_driver.run(os.path.join(tmp, "db"), imset, os.path.join(tmp, f"fq{lanes}"), prop, fuse, rounds=8, lanes=lanes)),
-                         ("eval_driver", lambda: eval_driver.run(os.path.join(tmp, "db"), imset, os.path.join(tmp, "e.csv"), prop, fuse, "oracle_mask", rounds=8, lanes=lanes))):
+        for name, fn in (("fq_driver", lambda st: fq_driver.run(os.path.join(tmp, "db"), imset, os.path.join(tmp, f"fq{lanes}"), prop, fuse, rounds=8, lanes=lanes, stats=st)),
+                         ("eval_driver", lambda st: eval_driver.run(os.path.join(tmp, "db"), imset, os.path.join(tmp, "e.csv"), prop, fuse, "oracle_mask", rounds=8, lanes=lanes, stats=st))):
             torch.cuda.synchronize()
+            st = {}
             t0 = time.perf_counter()
-            rows = fn()
+            rows = fn(st)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
-            print(f"lanes {lanes} {name}: {len(rows)} rounds in {dt:.2f} s = {len(rows) / dt:.1f} rounds/s = {len(rows) * (T - 1) / dt:.0f} propagated frames/s", flush=True)
+            print(f"lanes {lanes} {name}: {len(rows)} rounds in {dt:.2f} s = {len(rows) / dt:.1f} rounds/s = {st.get('propagated_frames', 0) / dt:.0f} propagated frames/s; "
+                  f"host account {st}", flush=True)
