@@ -372,9 +372,20 @@ def save_rgb_frames(rgb: torch.Tensor, out_dir: str, pool=None):
     small = torch.nn.functional.interpolate(rgb.float(), size=(224, 224), mode="bicubic", align_corners=False, antialias=True)
     lo = small.amin((1, 2, 3), keepdim=True)
     hi = small.amax((1, 2, 3), keepdim=True)
-    frames = ((small - lo) / (hi - lo).clamp_min(1e-8) * 255).to(torch.uint8).permute(0, 2, 3, 1).cpu().numpy()
+    dev8 = ((small - lo) / (hi - lo).clamp_min(1e-8) * 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+    if pool is None or not dev8.is_cuda:
+        frames, ready = dev8.cpu().numpy(), None
+    else:                                                           # as save_state_masks: the WRITER waits for the download, not the lane
+        host = torch.empty(dev8.shape, dtype=torch.uint8, pin_memory=True)
+        host.copy_(dev8, non_blocking=True)
+        ready = torch.cuda.Event(blocking=True)
+        ready.record()
+        dev8.record_stream(torch.cuda.current_stream())
+        frames = host.numpy()
 
     def write():
+        if ready is not None:
+            ready.synchronize()
         os.makedirs(out_dir, exist_ok=True)
         for t, m in enumerate(frames):
             write_png(os.path.join(out_dir, f"{t:05d}.png"), m)
