@@ -177,6 +177,10 @@ def _pad16(n: int):
     return lo, d - lo
 
 
+# measurement aid (tools/driver_lanes.py): when set to a dict, InferenceCore.__init__ adds the host seconds of its phases to it
+CREATE_ACCOUNT = None
+
+
 class InferenceCore:
     def __init__(self, prop_net, fuse_net, images, num_objects, mem_profile=0, mem_freq=5, device="cuda", engine_options=None):
         """``engine_options`` (not in the reference; results never depend on it): dict with any of ``lookahead``, ``decode_batch``,
@@ -199,7 +203,9 @@ class InferenceCore:
         self.pad = (lw, uw, lh, uh)
         self.nh, self.nw = self.h + lh + uh, self.w + lw + uw
         self.kh, self.kw = self.nh // 16, self.nw // 16
+        t_0 = time.perf_counter()
         self._model = _model_for(prop_net, fuse_net, self.device.index or 0)
+        t_1 = time.perf_counter()
         with torch.cuda.device(self.device):
             self._stream = torch.cuda.current_stream()
             def alloc():
@@ -215,6 +221,7 @@ class InferenceCore:
                 torch.cuda.empty_cache()
                 imgs, self.prob, self.masks = alloc()
             self.np_masks = np.zeros((self.t, self.h, self.w), dtype=np.uint8)
+            t_2 = time.perf_counter()
             h_ = C.c_void_p()
             eo = dict(engine_options or {})
             opts = _lib.EngineOpts(*(int(eo.pop(n, -1)) for n, _ in _lib.EngineOpts._fields_))
@@ -223,6 +230,11 @@ class InferenceCore:
             _lib.check(_lib.lib().stcn_engine_create_ex(
                 self._model.handle, self.t, self.h, self.w, self.k, int(mem_freq), self._stream.cuda_stream,
                 imgs.data_ptr(), self.prob.data_ptr(), self.masks.data_ptr(), C.byref(opts), C.byref(h_)), "stcn_engine_create")
+        if CREATE_ACCOUNT is not None:
+            t_3 = time.perf_counter()
+            with _MODEL_LOCK:
+                for k_, v_ in (("model_for_s", t_1 - t_0), ("torch_alloc_s", t_2 - t_1), ("engine_create_s", t_3 - t_2)):
+                    CREATE_ACCOUNT[k_] = CREATE_ACCOUNT.get(k_, 0.0) + v_
         self._images_unpadded = imgs
         self._engine = h_
         self._finalizer = weakref.finalize(self, _lib.lib().stcn_engine_destroy, h_)
