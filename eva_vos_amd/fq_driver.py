@@ -41,17 +41,92 @@ _DECODE_POOL = None
 _DECODE_LOCK = __import__("threading").Lock()
 
 
+class _DecodeProcs:
+    """A pool of image-decode worker PROCESSES (eva_vos_amd/_decode_worker.py: NumPy + Pillow only) fed over pipes; the pixels come back
+    through shared memory.  Threads would do the decoding itself just as well (Pillow releases the interpreter lock inside its codecs) but
+    they take that lock thousands of times per video around the codec calls - and the lanes that drive the GPU share it (round 6:
+    building one InferenceCore, 0.9 ms of Python, took 30-60 ms beside 16 decode threads)."""
+
+    def __init__(self, n: int):
+        import atexit
+        import queue
+        import subprocess
+        import sys
+        from concurrent.futures import ThreadPoolExecutor
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        self.idle = queue.Queue()
+        self.procs = [subprocess.Popen([sys.executable, "-m", "eva_vos_amd._decode_worker"], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                                       text=True, bufsize=1, cwd=root, env=env) for _ in range(n)]
+        for p_ in self.procs:
+            self.idle.put(p_)
+        self.waiters = ThreadPoolExecutor(n, thread_name_prefix="stcn-decode-wait")      # threads that only block on a worker's pipe
+        atexit.register(self.close)
+
+    def close(self):
+        for p_ in self.procs:
+            try:
+                p_.stdin.close()
+            except OSError:
+                pass
+        self.procs = []
+
+    def _call(self, req: dict):
+        import json
+        p_ = self.idle.get()
+        try:
+            p_.stdin.write(json.dumps(req) + "\n")
+            p_.stdin.flush()
+            ans = p_.stdout.readline()
+        finally:
+            self.idle.put(p_)
+        if not ans.startswith("ok"):
+            raise RuntimeError(f"image-decode worker: {ans.strip() or 'died'}")
+
+    def decode(self, jpgs, pngs, H: int, W: int):
+        """uint8 [T,H,W,3] frames and [T,H,W] label maps of one video (either list may be None), decoded by the workers in chunks."""
+        from multiprocessing import shared_memory
+        T = len(jpgs if jpgs is not None else pngs)
+        rgb = shared_memory.SharedMemory(create=True, size=T * H * W * 3) if jpgs is not None else None
+        lab = shared_memory.SharedMemory(create=True, size=T * H * W) if pngs is not None else None
+        try:
+            step = max(1, -(-T // (2 * len(self.procs))))
+            futs = []
+            for f0 in range(0, T, step):
+                frames = [[t, jpgs[t] if jpgs is not None else None, pngs[t] if pngs is not None else None] for t in range(f0, min(T, f0 + step))]
+                futs.append(self.waiters.submit(self._call, {"rgb": rgb.name if rgb else None, "lab": lab.name if lab else None, "shape": [T, H, W], "frames": frames}))
+            for f in futs:
+                f.result()
+            u8 = np.ndarray((T, H, W, 3), np.uint8, buffer=rgb.buf).copy() if rgb else None
+            lb = np.ndarray((T, H, W), np.uint8, buffer=lab.buf).copy() if lab else None
+            return u8, lb
+        finally:
+            for m in (rgb, lab):
+                if m is not None:
+                    m.close()
+                    m.unlink()
+
+
 def decode_pool():
-    """The process-wide pool of image-decode threads (STCN_DECODE_THREADS, default min(16, host cores / 2); 0 = decode inline).  Shared by
-    every lane's loader: what matters is that the NEXT sample of every lane is ready when the lane asks for it, not who decodes it."""
+    """The process-wide image-decode pool shared by every lane's loader (what matters is that the NEXT sample of every lane is ready when
+    the lane asks for it, not who decodes it).  STCN_DECODE_PROCS worker processes (default min(8, host cores / 4); see _DecodeProcs);
+    STCN_DECODE_PROCS=0: a pool of STCN_DECODE_THREADS threads instead (default min(16, cores / 2); 0 = decode inline)."""
     global _DECODE_POOL
-    n = int(os.environ.get("STCN_DECODE_THREADS", min(16, max(1, (os.cpu_count() or 2) // 2))))
-    if n <= 0:
+    cores = os.cpu_count() or 2
+    n_proc = int(os.environ.get("STCN_DECODE_PROCS", min(8, max(1, cores // 4))))
+    n_thr = int(os.environ.get("STCN_DECODE_THREADS", min(16, max(1, cores // 2))))
+    if n_proc <= 0 and n_thr <= 0:
         return None
     with _DECODE_LOCK:
         if _DECODE_POOL is None:
-            from concurrent.futures import ThreadPoolExecutor
-            _DECODE_POOL = ThreadPoolExecutor(n, thread_name_prefix="stcn-decode")
+            if n_proc > 0 and os.path.isdir("/dev/shm"):
+                try:
+                    _DECODE_POOL = _DecodeProcs(n_proc)
+                except OSError:
+                    _DECODE_POOL = None
+            if _DECODE_POOL is None and n_thr > 0:
+                from concurrent.futures import ThreadPoolExecutor
+                _DECODE_POOL = ThreadPoolExecutor(n_thr, thread_name_prefix="stcn-decode")
         return _DECODE_POOL
 
 
@@ -95,7 +170,11 @@ class ClipDataset:
                 return np.array(Image.open(os.path.join(self.mask_dir, video, f"{f:05d}.png")).convert("P"), dtype=np.uint8)
 
             pool = decode_pool()
-            if pool is None:
+            if isinstance(pool, _DecodeProcs):
+                w_, h_ = Image.open(os.path.join(self.image_dir, video, "00000.jpg")).size        # header only
+                u8, lab = pool.decode([os.path.join(self.image_dir, video, f"{f:05d}.jpg") for f in range(n)],
+                                      [os.path.join(self.mask_dir, video, f"{f:05d}.png") for f in range(n)], h_, w_)
+            elif pool is None:
                 u8, lab = np.stack([frame(f) for f in range(n)]), np.stack([label(f) for f in range(n)])
             else:
                 fr, lb = [pool.submit(frame, f) for f in range(n)], [pool.submit(label, f) for f in range(n)]

@@ -111,26 +111,42 @@ class _Model:
 _MODEL_LOCK = threading.Lock()
 
 
+_FP_TENSORS: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()      # module -> (time of the last state_dict() walk, weak refs to its tensors)
+_FP_RESCAN_S = float(os.environ.get("STCN_FINGERPRINT_RESCAN_S", "2.0"))
+
+
 def _fingerprint(module) -> tuple:
     """(storage address, in-place version) of every tensor of the state_dict - changes when a checkpoint is loaded into the
     module (load_state_dict copies in place and bumps the versions) or a parameter is replaced - plus a content probe of a
     few tensors: writes through ``p.data`` (``p.data.copy_()``, ``p.data.mul_()``) do NOT bump ``_version``; the probe
     (sums over the first 4096 elements of 8 tensors spread over the state_dict) catches a whole-model update done that
     way.  Limitation, by design of a snapshot: a ``.data`` write confined to tensors outside the probe is not seen - call
-    ``eva_vos_amd.inference_core.forget_models()`` after such surgery (the reference reads live parameters)."""
+    ``eva_vos_amd.inference_core.forget_models()`` after such surgery (the reference reads live parameters).
+    Round 6: this runs once per InferenceCore, i.e. once per SAMPLE in the reference-style drivers, from lane threads that share the
+    interpreter with image-decode and PNG-writer threads - the 0.6 ms of Python below took 30-60 ms there (GIL hand-offs; measured by
+    tools/driver_lanes.py).  The walk over ``state_dict()`` (the bulk of it) is therefore repeated at most every STCN_FINGERPRINT_RESCAN_S
+    seconds per module; in between the tensors found by the last walk are checked (weak references: a parameter that was replaced and
+    freed forces a new walk at once), addresses, versions and content probe as before."""
     if module is None:
         return ()
-    sd = list(module.state_dict(keep_vars=True).values())
+    now = time.monotonic()
+    hit = _FP_TENSORS.get(module)
+    sd = None
+    if hit is not None and now - hit[0] < _FP_RESCAN_S:
+        sd = [r() for r in hit[1]]
+        if any(t is None for t in sd):
+            sd = None
+    if sd is None:
+        sd = list(module.state_dict(keep_vars=True).values())
+        _FP_TENSORS[module] = (now, [weakref.ref(t) for t in sd])
     ids = tuple((v.data_ptr(), v._version) for v in sd)
     fl = [v for v in sd if v.is_floating_point() and v.numel() > 0]
-    probe = []
-    for i in sorted({(len(fl) - 1) * j // 7 for j in range(8)}) if fl else ():
-        x = fl[i].detach().reshape(-1)[:4096].double()
-        probe += [x.sum(), x.abs().sum()]
-    # ONE device-to-host transfer (and host sync) per module for all probes: the reference-style drivers build one core per sample
-    # from several lane threads, 16 blocking float() calls per module serialised them
-    vals = tuple(torch.stack([v.to(probe[0].device) for v in probe]).tolist()) if probe else ()
-    return ids + vals
+    if not fl:
+        return ids
+    # the content probe as ONE concatenated slice (two reductions, one host transfer: the reference-style drivers build one core per
+    # sample from several lane threads; 16 blocking float() calls per module once serialised them)
+    x = torch.cat([fl[i].detach().reshape(-1)[:4096] for i in sorted({(len(fl) - 1) * j // 7 for j in range(8)})]).double()
+    return ids + tuple(torch.stack([x.sum(), x.abs().sum(), (x * x).sum()]).tolist())
 
 
 _SNAPSHOTS_PER_DEVICE = 4      # LRU: alternating a few (prop_net weights, fuse_net) pairs must not re-fold the model every time
