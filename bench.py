@@ -440,6 +440,9 @@ def main():
             "host_cpu_s_per_lane": [round(v, 3) for v in host_acct["lane_cpu_s"]],
             "host_cpu_s_per_video": sum(host_acct["lane_cpu_s"]) / max(host_acct["videos"], 1),
             "host_cores": os.cpu_count(),
+            # interact() downloads of this process that did NOT get a pinned block (per-core budget of 4 blocks, 4 GB per process): 0 = every
+            # download of every leg took the one-DMA path
+            "pageable_downloads": __import__("eva_vos_amd.inference_core", fromlist=["x"]).pageable_downloads(),
         }
         if r2 is not None:
             out["r2_frames_per_s_rank0"] = r2

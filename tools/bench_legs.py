@@ -576,7 +576,11 @@ def drivers_leg(prop, fuse, H, W, videos, frames, lanes=2, rounds=8):
             # propagated frames = what the engines' do_pass really visited (stcn_get_stats per interaction): rounds >= 2 walk only the spans
             # between the new annotation and its neighbours (round 5 multiplied rounds by T - 1: 4-5 x too many)
             out[name] = {"rounds": int(len(rows)), "seconds": dt, "rounds_per_s": len(rows) / dt, "propagated_frames": int(st.get("propagated_frames", 0)),
-                         "propagated_frames_per_s": st.get("propagated_frames", 0) / dt, "frames_per_round_mean": st.get("propagated_frames", 0) / max(len(rows), 1)}
+                         "propagated_frames_per_s": st.get("propagated_frames", 0) / dt, "frames_per_round_mean": st.get("propagated_frames", 0) / max(len(rows), 1),
+                         # where the lanes' wall time went (host clock, summed over the samples of a lane): waiting for the loader, building
+                         # InferenceCores, the annotation sessions themselves (GPU-bound: the `session` leg is their resident-clip limit)
+                         "host_account": {"lanes": st.get("lanes"), "create_s": round(st.get("create_s", 0.0), 4), "session_s": round(st.get("session_s", 0.0), 4),
+                                          "wait_writers_s": st.get("wait_writers_s")}}
         out["what"] = ("rounds/s incl. JPEG decode, H2D, propagation (1 first + 7 later interactions per sample), GPU J / J&F and all output files; "
                        "reference counterparts: generate_fq_dataset.py:60-86, eval_annotation_method.py:118-190 with interactions/mask.py:113-146")
         return out

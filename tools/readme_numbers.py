@@ -19,6 +19,10 @@ rows = [
     ("config 3: one 5-object engine, mem_freq=1, T=104 (portrait 854×480, T=52)", f"{c3['frames_per_s']:.0f} ({c3['portrait']['frames_per_s']:.0f}) frames/s"),
     ("30 DAVIS-val lengths, 5 of them portrait, LPT", f"{d['davis_val']['frames_per_s']:.0f} frames/s"),
     ("configs 4 / 5 end to end (fq_driver / eval_driver, 8 videos × 40 frames, 2 lanes)", f"{dr['fq_driver']['rounds_per_s']:.1f} / {dr['eval_driver_oracle_mask']['rounds_per_s']:.1f} rounds/s"),
+    ("annotation sessions on resident clips, oracle policy: 8 rounds × 40 frames / 60 rounds × 66 frames (one lane → most lanes)",
+     " / ".join(f"{v['lanes']['1']['rounds_per_s']:.1f} → {max(x['rounds_per_s'] for x in v['lanes'].values()):.1f} rounds/s ({v['lanes']['1']['propagated_frames_per_s']:.0f} → "
+                f"{max(x['propagated_frames_per_s'] for x in v['lanes'].values()):.0f} propagated frames/s, device busy {v['lanes']['1']['device_busy_frac']:.2f} at one lane)"
+                for v in (d["session"]["config4_shape"], d["session"]["config5_shape"])) if d.get("session") and "error" not in d["session"] else "not measured"),
     ("conv GEMMs (fp32 MFMA), executed FLOP / kernel time", f"{d['roofline']['achieved']:.1f} TFLOP/s = **{d['roofline']['frac']:.3f}** of 157.3 ({d['roofline']['algorithmic_tflops_incl_transforms']:.0f} algorithmic); whole frame {d['roofline']['frame_executed_frac']:.3f}; kernel time per R1 frame {d['frame_kernel_ms']:.2f} ms"),
     ("memory read alone, T=104, k=5 (random keys)", f"{d['roofline_memread']['frac']:.3f} of the fp32 MFMA peak"),
     ("CPU oracle on the box's host cores (BASELINE config 1)", f"{c['r1_frames_per_s']:.2f} / {c['r2_frames_per_s']:.2f} frames/s (R1 / R2, {c['threads']} threads of {c['host_cores']} cores)"),
