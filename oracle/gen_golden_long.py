@@ -1,0 +1,90 @@
+"""Capture LONG-HORIZON golden masks from the REAL reference (build container only) -> tests/golden/long_*.npz.
+
+Same import shims as oracle/gen_golden.py.  Round 6: the long parity legs (a 24-round annotation session, BASELINE config 3 at its full
+length) compared the HIP engine with the CPU oracle only - both are "other" fp32 implementations of the reference.  Here the reference
+itself produces the masks of those runs, so that `-m gpu` tests (HIP only: seconds) state long-horizon parity against the REFERENCE:
+
+  long_sess24   480x854, k = 1, T = 34, mem_freq = 5 (clip / ground truth seed 7, as bench.py's session leg): 24 rounds of the oracle
+                mask policy (interactions/mask.py:113-146: annotate frame 0, then the frame with the worst J against the ground truth,
+                annotated frames counting with their ground truth) driven by the reference's OWN 8-thread masks.  Stored: the annotated
+                frames, the packed masks of every round, and per round the reference's own spread between its 8-thread and 1-thread
+                executions of the same session (selfnoise columns: clip 1-IoU, max / p99.9 |dprob|, differing px, worst frame 1-IoU) -
+                the yardstick of how far two executions of the reference drift apart over 24 rounds.
+  long_cfg3     480x854, k = 5 (scribble path, multi-object recipe seed 2), mem_freq = 1, T = 104: interact(mask, 0), the label map of
+                all 104 frames (8 threads).
+
+Run:  python oracle/gen_golden_long.py sess24 | cfg3        (~50 min / ~15 min on 8 cores)
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.argv, _args = sys.argv[:1], sys.argv[1:]
+import gen_golden as G  # noqa: E402  (sets up the reference import path; same directory)
+
+from eva_vos_amd import synth  # noqa: E402
+
+GOLD = G.GOLD
+
+
+def frame_rows(a, b, T):
+    a, b = a.reshape(T, -1), b.reshape(T, -1)
+    u, n = (a | b).sum(1), (a & b).sum(1)
+    ok = u >= 64
+    return float((1.0 - n[ok] / u[ok]).max()) if ok.any() else 0.0
+
+
+def sess24(rounds=24, T=34, H=480, W=854, mem_freq=5):
+    net, fus, _, _ = G.load_reference()
+    img, msk = synth.synthetic_clip(T, H, W, seed=7), synth.synthetic_mask(T, H, W, 1, seed=7)
+    gtb = msk[0, :, 0].numpy() > 0.5
+    cores = {nt: G.RefCore(net, fus, img, 1, mem_freq=mem_freq, device="cpu") for nt in (8, 1)}
+    out = {"shape": np.array([T, H, W, 1, mem_freq]), "seed": np.array(7)}
+    frames, noise = [0], np.zeros((rounds, 5))
+    for r in range(rounds):
+        f = frames[r]
+        res = {}
+        for nt, core in cores.items():                      # the SAME annotation sequence on both executions (the 8-thread run decides it)
+            torch.set_num_threads(nt)
+            t0 = time.time()
+            res[nt] = core.interact(msk[:, f].clone(), f).copy()
+            print(f"round {r + 1} frame {f} threads {nt}: {time.time() - t0:.0f} s", flush=True)
+        a, b = res[8] > 0, res[1] > 0
+        u = (a | b).sum()
+        d = (cores[8].prob - cores[1].prob).abs()
+        noise[r] = [0.0 if u == 0 else 1.0 - float((a & b).sum() / u), float(d.max()), float(torch.quantile(d.flatten()[::7], 0.999)),
+                    float((a != b).sum()), frame_rows(a, b, T)]
+        out[f"r{r}.masks"] = np.packbits(a, axis=None)
+        gen = a.copy()
+        done = sorted(set(frames))
+        gen[done] = gtb[done]
+        uu, nn = (gen | gtb).reshape(T, -1).sum(1), (gen & gtb).reshape(T, -1).sum(1)
+        q = np.where(uu > 0, nn / np.maximum(uu, 1), 0.0)
+        frames.append(int(np.argmin(q)))
+        print(f"   selfnoise {noise[r].tolist()} next frame {frames[-1]}", flush=True)
+    out["frames"] = np.array(frames[:rounds])
+    out["selfnoise"] = noise
+    np.savez_compressed(os.path.join(GOLD, "long_sess24.npz"), **out)
+    print("wrote long_sess24.npz", os.path.getsize(os.path.join(GOLD, "long_sess24.npz")))
+
+
+def cfg3(T=104, H=480, W=854, k=5):
+    net, fus, _, _ = G.load_reference(2)
+    torch.set_num_threads(8)
+    img, msk = synth.synthetic_clip(T, H, W), synth.synthetic_mask(T, H, W, k)
+    m0 = torch.cat([1 - msk[:, 0].sum(0, keepdim=True).clamp(0, 1), msk[:, 0]], 0)
+    t0 = time.time()
+    core = G.RefCore(net, fus, img, k, mem_freq=1, device="cpu")
+    masks = core.interact(m0.clone(), 0, scribble=True)
+    print(f"reference: {T} frames k={k} in {time.time() - t0:.0f} s")
+    np.savez_compressed(os.path.join(GOLD, "long_cfg3.npz"), masks=masks.astype(np.uint8), shape=np.array([T, H, W, k, 1]), seed=np.array(2))
+    print("wrote long_cfg3.npz", os.path.getsize(os.path.join(GOLD, "long_cfg3.npz")))
+
+
+if __name__ == "__main__":
+    {"sess24": sess24, "cfg3": cfg3}[_args[0]]()

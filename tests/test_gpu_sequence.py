@@ -912,6 +912,59 @@ def test_a_480p_session_cloned_mid_way_continues_on_both_branches(nets, weights)
     assert np.array_equal(last, a2) and torch.equal(fresh.prob, twin.prob)
 
 
+def _long_golden(name):
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"{name}.npz")
+    if not os.path.exists(path):
+        pytest.skip(f"{name}.npz not captured (oracle/gen_golden_long.py, build container only)")
+    return dict(np.load(path))
+
+
+def test_twenty_four_round_session_matches_the_reference_itself(nets):
+    """Long-horizon parity against the REFERENCE, not the oracle: tests/golden/long_sess24.npz holds the masks of all 24 rounds of the oracle
+    mask policy (interactions/mask.py:113-146) that the reference itself produced on the 34-frame 480x854 clip of bench.py's session leg
+    (oracle/gen_golden_long.py), the frames it annotated, and per round how far its own 8-thread and 1-thread executions of that session
+    drift apart.  The HIP engine follows the same annotations; per round: clip 1-IoU <= max(1e-3, 1.5 x the reference's own clip spread of
+    that round), every frame <= max(1e-3, 1.5 x the reference's own worst frame of that round, 2 px / union px)."""
+    g = _long_golden("long_sess24")
+    T, H, W, k, mf = (int(v) for v in g["shape"])
+    seed = int(g["seed"])
+    img, msk = synth.synthetic_clip(T, H, W, seed=seed), synth.synthetic_mask(T, H, W, 1, seed=seed)
+    core = make_core(nets)(img, 1, mf)
+    worst = [0.0, 0.0]
+    for r, f in enumerate(int(v) for v in g["frames"]):
+        a = core.interact(msk[:, f], f) > 0
+        b = np.unpackbits(g[f"r{r}.masks"])[: T * H * W].reshape(T, H, W).astype(bool)
+        noise = g["selfnoise"][r]
+        vol = 1 - iou(a, b)
+        miss, fr = frame_miss(a, b)
+        px = (a[fr] | b[fr]).sum() if fr >= 0 else 1
+        vb, fb = clip_bound(noise[0]), frame_bound(noise[4], px)
+        worst = [max(worst[0], vol / vb), max(worst[1], miss / fb)]
+        print(f"HIP vs REFERENCE session round {r + 1} (frame {f}): clip 1-IoU {vol:.2e} (bound {vb:.1e}; reference vs itself {noise[0]:.2e}), worst frame {fr}: "
+              f"{miss:.2e} (bound {fb:.1e}; reference vs itself {noise[4]:.2e}), {int((a != b).sum())} px differ (reference vs itself {int(noise[3])})")
+        assert vol <= vb and miss <= fb, (r, f, vol, vb, fr, miss, fb)
+    print(f"worst measured / bound over the session: clip {worst[0]:.2f}, frame {worst[1]:.2f}")
+    assert core.stats()["bank_fwd"] >= 24
+
+
+def test_config3_at_full_length_matches_the_reference_itself(nets_multi):
+    """BASELINE config 3 as stated - 480x854, five objects through the scribble path, every frame in the bank, T = 104 - against the label map
+    the REFERENCE produced for all 104 frames (tests/golden/long_cfg3.npz, oracle/gen_golden_long.py; multi-object recipe, all pixels): per
+    object the clip within the plain 1e-3, every frame within max(1e-3, 1.5 x the reference's own per-frame spread on the multi-object 480p
+    fixtures, 2 px / union px)."""
+    g = _long_golden("long_cfg3")
+    T, H, W, k, mf = (int(v) for v in g["shape"])
+    img, msk = synth.synthetic_clip(T, H, W), synth.synthetic_mask(T, H, W, k)
+    m0 = torch.cat([1 - msk[:, 0].sum(0, keepdim=True).clamp(0, 1), msk[:, 0]], 0)
+    core = make_core(nets_multi)(img, k, mf)
+    a, b = core.interact(m0, 0, scribble=True), g["masks"]
+    n = load_golden("selfnoise")
+    yard = np.max([n[t].max(0) for t in ("seq480k5", "seq480k3", "seq640k3", "cfg3full")], 0)
+    print(f"HIP vs REFERENCE config 3 full length: {int((a != b).sum())} of {a.size} px differ")
+    masks_close(a, b, k, "config 3 T=104 vs the reference", yard)
+    assert core.stats()["bank_fwd"] >= T - 2                     # every frame but the last entered the bank
+
+
 _POOL_SCRIPT = r"""
 import sys, torch
 sys.path.insert(0, %r)
