@@ -920,10 +920,10 @@ def _long_golden(name):
 
 
 def test_twenty_four_round_session_matches_the_reference_itself(nets):
-    """Long-horizon parity against the REFERENCE, not the oracle: tests/golden/long_sess24.npz holds the masks of all 24 rounds of the oracle
+    """Long-horizon parity against the REFERENCE, not the oracle: tests/golden/long_sess24.npz holds the masks after rounds 8, 16 and 24 of the oracle
     mask policy (interactions/mask.py:113-146) that the reference itself produced on the 34-frame 480x854 clip of bench.py's session leg
     (oracle/gen_golden_long.py), the frames it annotated, and per round how far its own 8-thread and 1-thread executions of that session
-    drift apart.  The HIP engine follows the same annotations; per round: clip 1-IoU <= max(1e-3, 1.5 x the reference's own clip spread of
+    drift apart (all 24 rounds).  The HIP engine follows the same 24 annotations; at the stored rounds: clip 1-IoU <= max(1e-3, 1.5 x the reference's own clip spread of
     that round), every frame <= max(1e-3, 1.5 x the reference's own worst frame of that round, 2 px / union px)."""
     g = _long_golden("long_sess24")
     T, H, W, k, mf = (int(v) for v in g["shape"])
@@ -932,7 +932,10 @@ def test_twenty_four_round_session_matches_the_reference_itself(nets):
     core = make_core(nets)(img, 1, mf)
     worst = [0.0, 0.0]
     for r, f in enumerate(int(v) for v in g["frames"]):
-        a = core.interact(msk[:, f], f) > 0
+        a = core.interact(msk[:, f], f, download=f"r{r}.masks" in g)
+        if a is None:
+            continue                                            # the reference's masks are stored for rounds 8, 16 and 24 (1 MB each)
+        a = a > 0
         b = np.unpackbits(g[f"r{r}.masks"])[: T * H * W].reshape(T, H, W).astype(bool)
         noise = g["selfnoise"][r]
         vol = 1 - iou(a, b)
