@@ -330,6 +330,12 @@ __global__ __launch_bounds__(64 * W4W) void wino4_gemm_kernel(const Wino4G p, co
     // thread = (tile, 4 consecutive channels, half of the output columns): 16-byte LDS reads, residual loads and stores; the
     // first 8 waves work (32 tiles x 8 channel quads x 2 column pairs).  The residual block (+ bias) is requested before the
     // barrier - after the accumulators went to LDS, their registers are free - and is the start value of the output sums.
+    // eval-mode BatchNorm behind the conv (p.scale = alpha[n]; the bias below is its beta): the reference evaluates conv(x) * alpha + beta on
+    // the output of the UNSCALED conv.  Here M is multiplied by alpha on its way into the LDS exchange - a lane's accumulator column IS one
+    // output channel, so this costs one register and 48 multiplies per half - and the output transform, bias, residual and ReLU below run
+    // as for every other layer (Y = A^T (alpha M) A = alpha (A^T M A); K pieces carry the factor in their partial sums: the reduce adds only
+    // bias and residual).  Without a BatchNorm the factor is 1: the same bits as before.
+    const float sl = p.scale ? p.scale[tn * W4N + l31] : 1.f;
     const int chq = t & 7, tl = (t >> 3) & 31;
     const int jh = __builtin_amdgcn_readfirstlane(t >> 8);                    // wave-uniform: output columns 2 jh, 2 jh + 1
     const int tpi = p.TH * p.TW, ohw = p.OH * p.OW;
@@ -361,21 +367,12 @@ __global__ __launch_bounds__(64 * W4W) void wino4_gemm_kernel(const Wino4G p, co
         for (int pi = 0; pi < PPW; ++pi)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                smem[((pos0 + pi) * W4T + (r & 3) + 8 * (r >> 2) + 4 * h) * W4N + l31] = acc[pi][half][r];
-        f32x4 yv[2][4], bv = {0.f, 0.f, 0.f, 0.f}, sv = {1.f, 1.f, 1.f, 1.f};
+                smem[((pos0 + pi) * W4T + (r & 3) + 8 * (r >> 2) + 4 * h) * W4N + l31] = __fmul_rn(acc[pi][half][r], sl);
+        f32x4 yv[2][4], bv = {0.f, 0.f, 0.f, 0.f};
         if (p.bias && !kpiece) {
             int nb = n;
             asm volatile("" : "+v"(nb));                                      // per half: four registers not live across the other half
             bv = *reinterpret_cast<const f32x4 *>(p.bias + nb);
-        }
-        // eval-mode BatchNorm behind the conv, as the reference evaluates it (y * alpha + beta on the output of the UNSCALED conv): the
-        // sums of the output transform are built on their own, scaled, and only then meet bias and residual (scaled == false: the sums are
-        // built on top of residual + bias as before - the layers without BatchNorm keep their bits)
-        const bool scaled = p.scale != nullptr && !kpiece;                    // workgroup-uniform
-        if (scaled) {
-            int nb = n;
-            asm volatile("" : "+v"(nb));
-            sv = *reinterpret_cast<const f32x4 *>(p.scale + nb);
         }
         if (p.res && !kpiece && jh < 2) {
             const unsigned rb = (unsigned)(p.res_bmod ? b % p.res_bmod : b) * (unsigned)p.res_bs * 4u;
@@ -409,20 +406,12 @@ __global__ __launch_bounds__(64 * W4W) void wino4_gemm_kernel(const Wino4G p, co
                 zr[1] = (m[1] - m[2]) * 0.421875f + (m[3] - m[4]) * 3.375f + m[5];     // 27/64, 27/8
             }
         };
-        f32x4 rs[2][4];                                                       // scaled layers: residual parked here while yv collects the sums
         auto columns = [&](auto JH) {
             f32x4 za[2];
-            if (scaled) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int i2 = 0; i2 < 4; ++i2) { rs[j][i2] = yv[j][i2]; yv[j][i2] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int i2 = 0; i2 < 4; ++i2) yv[j][i2] += bv;
-            }
+                for (int i2 = 0; i2 < 4; ++i2) yv[j][i2] += bv;
             zrow(0, JH, za);
 #pragma unroll
             for (int j = 0; j < 2; ++j) yv[j][0] += za[j];
@@ -444,14 +433,6 @@ __global__ __launch_bounds__(64 * W4W) void wino4_gemm_kernel(const Wino4G p, co
             zrow(5, JH, za);
 #pragma unroll
             for (int j = 0; j < 2; ++j) yv[j][3] += za[j];
-            if (scaled) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int i2 = 0; i2 < 4; ++i2)
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) yv[j][i2][c] = __fadd_rn(__fadd_rn(__fmul_rn(yv[j][i2][c], sv[c]), bv[c]), rs[j][i2][c]);
-            }
         };
         if (jh == 0) columns(std::integral_constant<int, 0>{});
         else columns(std::integral_constant<int, 1>{});
@@ -504,8 +485,7 @@ __global__ __launch_bounds__(256) void wino4_reduce_kernel(const Wino4G p, const
     float v = 0.f;
 #pragma unroll
     for (int s2 = 0; s2 < 8; ++s2) v += s2 < p.pieces ? pv[s2] : 0.f;
-    if (p.scale) v = __fadd_rn(__fadd_rn(__fmul_rn(v, p.scale[n]), p.bias ? p.bias[n] : 0.f), rv);
-    else v += (p.bias ? p.bias[n] : 0.f) + rv;
+    v += (p.bias ? p.bias[n] : 0.f) + rv;                     // (a BatchNorm factor is already inside the partial sums: wino4_gemm_kernel)
     p.y[(p.y_bs ? (long)b * p.y_bs : (long)b * ohw * p.N) + po] = fmaxf(v, p.relu_out ? 0.f : -__builtin_inff());
 }
 
