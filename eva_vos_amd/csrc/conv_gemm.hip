@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256, (RM == 1 && RN == 1) ? STCN_PW_WAVES : 1) void
                 }
                 continue;
             }
-            const float bv = p.bias ? p.bias[n] : 0.f, sv = p.scale ? p.scale[n] : 1.f;      // y = acc * scale + bias (scale 1: bit-identical to acc + bias)
+            const float bv = p.bias ? p.bias[n] : 0.f;
             if (p.affine_out) {
                 // dense [M][N] output (and residual): buffer stores / loads, one address add per row; rows beyond M are dropped
                 // by the hardware range check of the vector offset (first version: ~8 address / predicate VALU ops per row,
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256, (RM == 1 && RN == 1) ? STCN_PW_WAVES : 1) void
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const unsigned vo = v0 + (unsigned)((r & 3) + 8 * (r >> 2)) * n4;
-                    const float v = fmaxf(__fadd_rn(__fmul_rn(c[r], sv), bv) + rv[r], lo);
+                    const float v = fmaxf(c[r] + bv + rv[r], lo);
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, vo, 0, 0);
                 }
                 continue;
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256, (RM == 1 && RN == 1) ? STCN_PW_WAVES : 1) void
             const float lo = p.relu_out ? 0.f : -__builtin_inff();
             float ov[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { ov[r] = fmaxf(__fadd_rn(__fmul_rn(c[r], sv), bv) + rv[r], lo); asm volatile("" : "+v"(ov[r])); }   // pinned: hipcc sinks it into the masked blocks otherwise
+            for (int r = 0; r < 16; ++r) { ov[r] = fmaxf(c[r] + bv + rv[r], lo); asm volatile("" : "+v"(ov[r])); }   // pinned: hipcc sinks it into the masked blocks otherwise
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 if (mbase + (r & 3) + 8 * (r >> 2) < p.M) p.y[yo[r]] = ov[r];
@@ -554,14 +554,13 @@ __global__ __launch_bounds__(256, STCN_PW_WAVES) void pw_chain_kernel(const Conv
     float rpre[16];
     unsigned v0 = OOB;                                 // byte offset of (first row, column) of this lane's accumulator block; OOB: column >= N
     const unsigned n4 = (unsigned)p.N * 4u;
-    float bv = 0.f, sv = 1.f;
+    float bv = 0.f;
     auto tile_begin = [&](int tile) {                  // output coordinates of the tile, its bias and its residual block (in flight under the K loop)
         int tm, tn;
         tile_to_mn(tile, tiles_n, ntile, p.panel, td, tm, tn);
         const int n0 = tn * BN + wn * 32 + (lane & 31), mb0 = tm * BM + wm * 32 + 4 * (lane >> 5);
         v0 = n0 < p.N ? (unsigned)(((long)mb0 * p.N + n0) * 4) : OOB;
         bv = p.bias && n0 < p.N ? p.bias[n0] : 0.f;
-        sv = p.scale && n0 < p.N ? p.scale[n0] : 1.f;
         if (p.res) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
@@ -575,7 +574,7 @@ __global__ __launch_bounds__(256, STCN_PW_WAVES) void pw_chain_kernel(const Conv
     auto tile_end = [&]() {                            // epilogue of the finished tile; rows >= M lie beyond the descriptor range (dropped)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float v = fmaxf(__fadd_rn(__fmul_rn(acc[r], sv), bv) + rpre[r], lo);
+            const float v = fmaxf(acc[r] + bv + rpre[r], lo);
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, v0 + (unsigned)((r & 3) + 8 * (r >> 2)) * n4, 0, 0);
         }
 #pragma unroll
@@ -660,8 +659,7 @@ __global__ __launch_bounds__(256) void conv_reduce_kernel(const ConvP p) {
             const f32x4 u = *reinterpret_cast<const f32x4 *>(p.partial + s * slab + e);
             v += u;
         }
-        if (p.scale) { const f32x4 sc = *reinterpret_cast<const f32x4 *>(p.scale + n); v.x = __fmul_rn(v.x, sc.x); v.y = __fmul_rn(v.y, sc.y); v.z = __fmul_rn(v.z, sc.z); v.w = __fmul_rn(v.w, sc.w); }
-        if (p.bias) { const f32x4 bb = *reinterpret_cast<const f32x4 *>(p.bias + n); v.x = __fadd_rn(v.x, bb.x); v.y = __fadd_rn(v.y, bb.y); v.z = __fadd_rn(v.z, bb.z); v.w = __fadd_rn(v.w, bb.w); }
+        if (p.bias) v += *reinterpret_cast<const f32x4 *>(p.bias + n);
         long yo = e;
         if (p.res || p.y_bs) {
             const int b = p.B == 1 ? 0 : m / ohw;
@@ -692,8 +690,7 @@ __global__ __launch_bounds__(256) void conv_reduce_tiles_kernel(const ConvP p, c
     const float *src = p.partial + (long)rt * p.rem_split * (BM * BN) + row * BN + col;
     f32x4 v = *reinterpret_cast<const f32x4 *>(src);
     for (int s = 1; s < p.rem_split; ++s) v += *reinterpret_cast<const f32x4 *>(src + (long)s * (BM * BN));
-    if (p.scale) { const f32x4 sc = *reinterpret_cast<const f32x4 *>(p.scale + n); v.x = __fmul_rn(v.x, sc.x); v.y = __fmul_rn(v.y, sc.y); v.z = __fmul_rn(v.z, sc.z); v.w = __fmul_rn(v.w, sc.w); }
-    if (p.bias) { const f32x4 bb = *reinterpret_cast<const f32x4 *>(p.bias + n); v.x = __fadd_rn(v.x, bb.x); v.y = __fadd_rn(v.y, bb.y); v.z = __fadd_rn(v.z, bb.z); v.w = __fadd_rn(v.w, bb.w); }
+    if (p.bias) v += *reinterpret_cast<const f32x4 *>(p.bias + n);
     long yo = (long)m * p.N + n;
     if (p.res || p.y_bs) {
         const int ohw = p.OH * p.OW;

@@ -37,7 +37,6 @@ int make_wino_fusion12(Model &m, ConvW &cw, const std::vector<float> &w_host);  
 
 struct ConvW {
     float *w = nullptr, *bias = nullptr;   // device: [Cout][Kp], [Cout]
-    float *scale = nullptr;                // device: [Cout] eval-mode BatchNorm factor applied to the conv output before `bias` (nullptr: none)
     float *wino_u = nullptr;               // device: Winograd F(2x2,3x3) weights [16][Cin/8][Cout][8] (eligible 3x3 convs)
     float *wino4_u = nullptr;              // device: Winograd F(4x4,3x3) weights [36][Cin/8][Cout][8] (decoder layers)
     float bias0 = 0.f;                     // host copy of bias[0] (Cout == 1 convs)

@@ -58,14 +58,6 @@ int stcn_test_conv(void *stream, const float *x, const float *wgt, const float *
         RC(wv.alloc(w.wino_v_floats));
         w.wino_v = wv.p;
     }
-    DevBuf sc;
-    if (flags & 8) {                       // flags bit 3: an eval-mode BatchNorm behind the conv - y = conv(x) * scale[n] + bias[n] (+ res); scale[n] = 0.5 + (n % 13) / 8
-        std::vector<float> hs(Cout);
-        for (int n = 0; n < Cout; ++n) hs[n] = 0.5f + (float)(n % 13) * 0.125f;
-        RC(sc.alloc(Cout));
-        HIPCHK(hipMemcpy(sc.p, hs.data(), (size_t)Cout * 4, hipMemcpyHostToDevice));
-        cw.scale = sc.p;
-    }
     m.conv["t"] = cw;
     w.splitk_floats = (size_t)16 * 1024 * 1024;
     RC(ws.alloc(w.splitk_floats));

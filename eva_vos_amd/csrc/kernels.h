@@ -64,8 +64,6 @@ struct ConvP {
     int K, Kp;              // K = KH*KW*Cin, Kp = K rounded up to 32 (weights zero-padded)
     const float *w;         // [N][Kp], k ordered (kh, kw, cin)
     const float *bias;      // [N] or nullptr
-    const float *scale;     // [N] or nullptr: per-channel factor applied to the accumulator BEFORE the bias (eval-mode BatchNorm as the reference
-                            // evaluates it: y * alpha + beta on the output of the UNSCALED conv); nullptr = 1
     const float *res;       // residual [B][OH*OW][N] or nullptr
     long res_bs;            // batch stride of res (0 = broadcast)
     int res_bmod;           // > 0: the residual of batch element b is res + (b % res_bmod) * res_bs (a per-FRAME tensor under a

@@ -108,7 +108,7 @@ struct WinoG {
     unsigned v_bytes, u_bytes;
     int Mt, Mt_pad, KB, N;
     int TH, TW, OH, OW, B, M;
-    const float *bias, *scale, *res;
+    const float *bias, *res;
     long res_bs; int res_bmod;
     float *y; long y_bs;
     int relu_out;
@@ -240,9 +240,8 @@ __global__ __launch_bounds__(1024 / PPW) void wino_gemm_kernel(const WinoG p, co
                 for (int r = 0; r < 16; ++r)
                     smem[((pos0 + pi) * WT + 32 * bi + (r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l31] = acc[pi][bi][c][r];
         const int n = tn * WN + 32 * c + 4 * chq;
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f}, sv = {1.f, 1.f, 1.f, 1.f};
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
         if (p.bias && !part) bv = *reinterpret_cast<const f32x4 *>(p.bias + n);
-        if (p.scale && !part) sv = *reinterpret_cast<const f32x4 *>(p.scale + n);
         // the residual block of all passes is requested before the barrier (offsets clamped inside the image for the ragged last
         // tile row / column)
         unsigned po[NQ][2];
@@ -284,9 +283,7 @@ __global__ __launch_bounds__(1024 / PPW) void wino_gemm_kernel(const WinoG p, co
             const bool rok = 2 * ty + row < p.OH;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                f32x4 v;
-#pragma unroll
-                for (int c4 = 0; c4 < 4; ++c4) v[c4] = __fadd_rn(__fmul_rn(yv[e][c4], sv[c4]), bv[c4]) + rv[q][e][c4];
+                f32x4 v = yv[e] + bv + rv[q][e];
 #pragma unroll
                 for (int c4 = 0; c4 < 4; ++c4) v[c4] = fmaxf(v[c4], lo);
                 const bool ok = rok && 2 * tx + e < p.OW;
@@ -364,7 +361,7 @@ void wino_launch(const ConvP &p, float *V, size_t slab_floats, hipStream_t s, hi
     g.u_bytes = (unsigned)((size_t)16 * p.Cin * p.N * 4);
     g.Mt = Mt; g.Mt_pad = Mt_pad; g.KB = KB; g.N = p.N;
     g.TH = TH; g.TW = TW; g.OH = p.OH; g.OW = p.OW; g.B = p.B; g.M = p.M;
-    g.bias = p.bias; g.scale = p.scale; g.res = p.res; g.res_bs = p.res_bs; g.res_bmod = p.res_bmod; g.y = p.y; g.y_bs = p.y_bs; g.relu_out = p.relu_out;
+    g.bias = p.bias; g.res = p.res; g.res_bs = p.res_bs; g.res_bmod = p.res_bmod; g.y = p.y; g.y_bs = p.y_bs; g.relu_out = p.relu_out;
     const int tiles_m = Mt_pad / WT, tiles_n = p.N / WN, ntile = tiles_m * tiles_n;
     g.fd_tpi = fastdiv_make((unsigned)(TH * TW)); g.fd_tw = fastdiv_make((unsigned)TW);
     g.fd_ntile = fastdiv_make((unsigned)ntile); g.fd_tiles_n = fastdiv_make((unsigned)tiles_n);

@@ -144,7 +144,7 @@ struct Wino4G {
     unsigned v_bytes, u_bytes;
     int Mt, Mt_pad, KB, N;
     int TH, TW, OH, OW, B, M;
-    const float *bias, *scale, *res;
+    const float *bias, *res;
     long res_bs; int res_bmod;
     float *y; long y_bs;
     int relu_out;
@@ -330,12 +330,6 @@ __global__ __launch_bounds__(64 * W4W) void wino4_gemm_kernel(const Wino4G p, co
     // thread = (tile, 4 consecutive channels, half of the output columns): 16-byte LDS reads, residual loads and stores; the
     // first 8 waves work (32 tiles x 8 channel quads x 2 column pairs).  The residual block (+ bias) is requested before the
     // barrier - after the accumulators went to LDS, their registers are free - and is the start value of the output sums.
-    // eval-mode BatchNorm behind the conv (p.scale = alpha[n]; the bias below is its beta): the reference evaluates conv(x) * alpha + beta on
-    // the output of the UNSCALED conv.  Here M is multiplied by alpha on its way into the LDS exchange - a lane's accumulator column IS one
-    // output channel, so this costs one register and 48 multiplies per half - and the output transform, bias, residual and ReLU below run
-    // as for every other layer (Y = A^T (alpha M) A = alpha (A^T M A); K pieces carry the factor in their partial sums: the reduce adds only
-    // bias and residual).  Without a BatchNorm the factor is 1: the same bits as before.
-    const float sl = p.scale ? p.scale[tn * W4N + l31] : 1.f;
     const int chq = t & 7, tl = (t >> 3) & 31;
     const int jh = __builtin_amdgcn_readfirstlane(t >> 8);                    // wave-uniform: output columns 2 jh, 2 jh + 1
     const int tpi = p.TH * p.TW, ohw = p.OH * p.OW;
@@ -367,7 +361,7 @@ __global__ __launch_bounds__(64 * W4W) void wino4_gemm_kernel(const Wino4G p, co
         for (int pi = 0; pi < PPW; ++pi)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                smem[((pos0 + pi) * W4T + (r & 3) + 8 * (r >> 2) + 4 * h) * W4N + l31] = __fmul_rn(acc[pi][half][r], sl);
+                smem[((pos0 + pi) * W4T + (r & 3) + 8 * (r >> 2) + 4 * h) * W4N + l31] = acc[pi][half][r];
         f32x4 yv[2][4], bv = {0.f, 0.f, 0.f, 0.f};
         if (p.bias && !kpiece) {
             int nb = n;
@@ -485,7 +479,7 @@ __global__ __launch_bounds__(256) void wino4_reduce_kernel(const Wino4G p, const
     float v = 0.f;
 #pragma unroll
     for (int s2 = 0; s2 < 8; ++s2) v += s2 < p.pieces ? pv[s2] : 0.f;
-    v += (p.bias ? p.bias[n] : 0.f) + rv;                     // (a BatchNorm factor is already inside the partial sums: wino4_gemm_kernel)
+    v += (p.bias ? p.bias[n] : 0.f) + rv;
     p.y[(p.y_bs ? (long)b * p.y_bs : (long)b * ohw * p.N) + po] = fmaxf(v, p.relu_out ? 0.f : -__builtin_inff());
 }
 
@@ -605,7 +599,7 @@ void wino4_launch(const ConvP &p, float *V, size_t slab_floats, hipStream_t s, h
     g.u_bytes = (unsigned)((size_t)36 * p.Cin * p.N * 4);
     g.Mt = Mt; g.Mt_pad = Mt_pad; g.KB = KB; g.N = p.N;
     g.TH = TH; g.TW = TW; g.OH = p.OH; g.OW = p.OW; g.B = p.B; g.M = p.M;
-    g.bias = p.bias; g.scale = p.scale; g.res = p.res; g.res_bs = p.res_bs; g.res_bmod = p.res_bmod; g.y = p.y; g.y_bs = p.y_bs; g.relu_out = p.relu_out;
+    g.bias = p.bias; g.res = p.res; g.res_bs = p.res_bs; g.res_bmod = p.res_bmod; g.y = p.y; g.y_bs = p.y_bs; g.relu_out = p.relu_out;
     const int tiles_n = pl.tiles_n, mb = pl.mb, tiles_m = pl.tiles_m;
     g.fd_tpi = fastdiv_make((unsigned)(TH * TW)); g.fd_tw = fastdiv_make((unsigned)TW); g.fd_tiles_n = fastdiv_make((unsigned)tiles_n);
     g.full_wg = pl.full_wg; g.pieces = pl.pieces; g.kb_per_piece = pl.per; g.partial = p.partial;

@@ -46,8 +46,10 @@ def fold_bn(sd: dict) -> dict:
     ``_conv`` evaluates conv(x, weight) * alpha + beta, which is how the reference's BatchNorm evaluates on the CPU.
     (The name is historical.  Until round 6 the BatchNorm WAS folded into the weights here; against the reference's own label map of
     BASELINE config 3 at full length - 104 frames, five objects - the folded restatement differed on 3227 pixels of 42.6 M, this one on
-    1152, the reference against itself at 1 and 8 threads on 824: the rounding of a folded per-channel gain is coherent over the whole
-    image and does not average out through the following layers.  The HIP engine made the same change.)"""
+    1152, the reference against itself at 1 and 8 threads on 824: with the BatchNorm behind the conv this restatement's encoder convs are
+    the reference's own PyTorch kernels on the reference's own weights.  The HIP engine keeps the BatchNorm folded: its convolutions are
+    other fp32 algorithms anyway, and evaluating the BatchNorm behind them was measured - 2426 against 2333 differing pixels, headline
+    -0.5 % - profiles/r06_bn_unfolded_ab.txt.)"""
     sd = {k: v.detach().to(torch.float32).cpu() for k, v in sd.items() if v.is_floating_point()}
     bn_of = {}
     for name in sd:

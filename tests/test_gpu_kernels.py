@@ -153,40 +153,6 @@ def test_conv_matches_fp64_reference(B, H, W, Cin, Cout, K, s, flags, splitk, pa
             assert "chunks=2" in ran, ran
 
 
-def _bn_cases():
-    """every CONVS case a BatchNorm can sit behind (not the Cout = 1 kernels and the FusionNet kernels: those layers have none)"""
-    return [c + (p,) for c, p in zip(CONVS, PATHS) if c[4] > 1 and not (c[3] in (12, 32) and c[4] == 32 and c[5] == 3)]
-
-
-@pytest.mark.parametrize("B,H,W,Cin,Cout,K,s,flags,splitk,path", _bn_cases())
-def test_conv_with_a_batchnorm_behind_it_matches_fp64_reference(B, H, W, Cin, Cout, K, s, flags, splitk, path, monkeypatch):
-    """Round 6: eval-mode BatchNorm is no longer folded into the weights - every conv epilogue (direct, pointwise / chain, stem, F(2x2), F(4x4),
-    and the split-K / tail / K-piece reduce kernels) evaluates y = conv(x) * scale[n] + bias[n] (+ residual, ReLU) on the output of the
-    UNSCALED conv, as the reference's BatchNorm does.  Flags bit 3 of the stage hook puts scale[n] = 0.5 + (n % 13) / 8 behind the conv: same
-    shapes, same kernel families, same 2e-5 against fp64."""
-    g = torch.Generator().manual_seed(Cin * 131 + Cout * 7 + K + 1)
-    x = torch.randn(B, Cin, H, W, generator=g)
-    w = torch.randn(Cout, Cin, K, K, generator=g) * (2.0 / (Cin * K * K)) ** 0.5
-    b = torch.randn(Cout, generator=g) * 0.1
-    OH, OW = (H + 2 * (K // 2) - K) // s + 1, (W + 2 * (K // 2) - K) // s + 1
-    res = torch.randn(B, Cout, OH, OW, generator=g) if B == 2 else None
-    scale = 0.5 + (torch.arange(Cout) % 13).double() * 0.125
-    ref = F.conv2d((F.relu(x) if flags & 1 else x).double(), w.double(), None, stride=s, padding=K // 2) * scale.view(1, -1, 1, 1) + b.double().view(1, -1, 1, 1)
-    if res is not None:
-        ref = ref + res.double()
-    if flags & 2:
-        ref = F.relu(ref)
-    monkeypatch.setenv("STCN_WINO_MIN_CIN", "64")
-    y = torch.full((B, OH, OW, Cout), float("nan"), device="cuda")
-    call("stcn_test_conv", stream(), nhwc(x), dev(w.permute(0, 2, 3, 1)), dev(b), None if res is None else nhwc(res), y,
-         B, H, W, Cin, Cout, K, K, s, K // 2, flags | 8, splitk)
-    got = y.permute(0, 3, 1, 2).cpu().double()
-    assert torch.isfinite(got).all()
-    err = (got - ref).abs().max().item() / ref.abs().max().item()
-    assert err < 2e-5, err
-    assert last_path().startswith(path), (last_path(), path)
-
-
 #                B  H    W    Cin  Cout flags  (1x1 convs large enough for the chain kernel: >= 1536 tiles of 64x64)
 CHAIN_CASES = [(5, 120, 216, 64, 256, 2),      # res2 conv3: 2 K tiles per tile, 8100 tiles, residual + ReLU
                (5, 120, 216, 256, 64, 2),      # res2 conv1: one n-tile per row block - consecutive tiles walk down M
@@ -230,30 +196,6 @@ def test_pointwise_chain_kernel_equals_the_one_tile_instance(B, H, W, Cin, Cout,
             assert (outs[0] - outs[1]).abs().max().item() <= 2e-6 * ref.abs().max().item()
         else:
             assert torch.equal(outs[0], outs[1]), "the chain kernel must reproduce the one-tile instance bit for bit"
-
-
-def test_pointwise_chain_kernel_with_a_batchnorm_behind_it(monkeypatch):
-    """the chain kernel's epilogue with the per-channel scale (res2 conv3 of the key encoder: BatchNorm + residual + ReLU): against fp64, and
-    bit-identical to the one-tile pointwise instance"""
-    B, H, W, Cin, Cout, flags = 5, 120, 216, 64, 256, 2
-    g = torch.Generator().manual_seed(99)
-    x = torch.randn(B, Cin, H, W, generator=g)
-    w = torch.randn(Cout, Cin, 1, 1, generator=g) * (2.0 / Cin) ** 0.5
-    b = torch.randn(Cout, generator=g) * 0.1
-    res = torch.randn(B, Cout, H, W, generator=g)
-    scale = 0.5 + (torch.arange(Cout) % 13).double() * 0.125
-    ref = F.relu(F.conv2d(x.double(), w.double()) * scale.view(1, -1, 1, 1) + b.double().view(1, -1, 1, 1) + res.double())
-    outs = []
-    for chain in ("0", "2"):
-        monkeypatch.setenv("STCN_PW_CHAIN", chain)
-        y = torch.full((B, H, W, Cout), float("nan"), device="cuda")
-        call("stcn_test_conv", stream(), nhwc(x), dev(w.permute(0, 2, 3, 1)), dev(b), nhwc(res), y, B, H, W, Cin, Cout, 1, 1, 1, 0, flags | 8, 0)
-        assert last_path().startswith("direct_pointwise_chain" if chain != "0" else "direct_pointwise "), last_path()
-        outs.append(y.cpu())
-    got = outs[1].permute(0, 3, 1, 2).double()
-    assert (got - ref).abs().max().item() / ref.abs().max().item() < 2e-5
-    if "+tail" not in last_path():
-        assert torch.equal(outs[0], outs[1]) or (outs[0] - outs[1]).abs().max().item() <= 2e-6 * ref.abs().max().item()
 
 
 def _random_conv_cases():
