@@ -27,6 +27,9 @@ rows = [
     ("memory read alone, T=104, k=5 (random keys)", f"{d['roofline_memread']['frac']:.3f} of the fp32 MFMA peak"),
     ("CPU oracle on the box's host cores (BASELINE config 1)", f"{c['r1_frames_per_s']:.2f} / {c['r2_frames_per_s']:.2f} frames/s (R1 / R2, {c['threads']} threads of {c['host_cores']} cores)"),
     ("parity vs CPU oracle, BASELINE config 1 (T=82, 33.6 M px)", f"clip IoU {p['mask_iou_hip_vs_cpu_oracle_r1']:.5f} / {p['mask_iou_hip_vs_cpu_oracle_r2']:.5f}, worst frame {p['min_frame_iou_hip_vs_cpu_oracle_r1']:.5f} / {p['min_frame_iou_hip_vs_cpu_oracle_r2']:.5f}; {p['mask_pixels_differing_r1']} / {p['mask_pixels_differing_r2']} px differ (round 4: 4489 / 3606)"),
+    ("long horizons against the REFERENCE itself (`tests/golden/long_*`, measured once: `profiles/r06_bn_unfolded_ab.txt`)",
+     "24-round 480p session: inside the reference's own 1- vs 8-thread spread at every checkpoint (round 24: clip 5.6e-4 vs 6.2e-4); config 3 at T=104, k=5: 2333 of 42.6 M px differ "
+     "(reference vs itself 824), objects 1-2 ≤ 4.4e-4 on the clip, the small objects 3-5 1.0-1.8e-3 (above the 1e-3 bar)"),
     ("parity legs with coded bounds (T=104; 8-round session; config 3 k=5, 24 frames, all pixels)", f"worst frame {d['parity_long_clip']['min_frame_iou']:.5f}; {d['parity_session']['worst_round_min_frame_iou']:.5f}; worst object {c3['parity_vs_cpu_oracle']['mask_iou_vs_cpu_oracle']:.5f} — all `within_bound`: {wb}"),
 ]
 table = "| | |\n|---|---|\n" + "\n".join(f"| {a} | {b} |" for a, b in rows) + "\n"
