@@ -120,5 +120,37 @@ def cfg3_noise1(T=104, H=480, W=854, k=5):
     np.save(os.path.join(GOLD, "..", "..", "gpurun_out", "cfg3_ref_1thread_masks.npy"), a.astype(np.uint8))
 
 
+def cfg3_24(T=24, H=480, W=854, k=5):
+    """The clip of bench.py's DEFAULT config-3 parity leg (the 24-frame synthetic clip - the synthetic clip depends on its length, so this is
+    not the head of the 104-frame one): the reference's label map at 8 threads -> tests/golden/long_cfg3_24.npz, and its own spread against a
+    1-thread execution -> selfnoise row `cfg3_24` (all five columns): the yardstick of exactly that leg.  ~12 min."""
+    net, fus, _, _ = G.load_reference(2)
+    img, msk = synth.synthetic_clip(T, H, W), synth.synthetic_mask(T, H, W, k)
+    m0 = torch.cat([1 - msk[:, 0].sum(0, keepdim=True).clamp(0, 1), msk[:, 0]], 0)
+    res = {}
+    for nt in (8, 1):
+        torch.set_num_threads(nt)
+        t0 = time.time()
+        core = G.RefCore(net, fus, img, k, mem_freq=1, device="cpu")
+        res[nt] = (core.interact(m0.clone(), 0, scribble=True).copy(), core.prob.clone())
+        print(f"reference {nt} thread(s): {time.time() - t0:.0f} s", flush=True)
+    (a, pa), (b, pb) = res[8], res[1]
+    worst, wf = 0.0, 0.0
+    for o in range(1, k + 1):
+        x, y = a == o, b == o
+        u = (x | y).sum()
+        worst = max(worst, 0.0 if u == 0 else 1.0 - float((x & y).sum() / u))
+        wf = max(wf, frame_rows(x, y, T))
+    d = (pa - pb).abs()
+    row = np.array([[worst, float(d.max()), float(torch.quantile(d.flatten()[::7], 0.999)), float((a != b).sum()), wf]])
+    print("selfnoise cfg3_24", row.tolist(), flush=True)
+    np.savez_compressed(os.path.join(GOLD, "long_cfg3_24.npz"), masks=a.astype(np.uint8), shape=np.array([T, H, W, k, 1]), seed=np.array(2))
+    path = os.path.join(GOLD, "selfnoise.npz")
+    sn = dict(np.load(path))
+    sn["cfg3_24"] = row
+    np.savez_compressed(path, **sn)
+    print("wrote long_cfg3_24.npz", os.path.getsize(os.path.join(GOLD, "long_cfg3_24.npz")))
+
+
 if __name__ == "__main__":
-    {"sess24": sess24, "cfg3": cfg3, "cfg3_noise1": cfg3_noise1}[_args[0]]()
+    {"sess24": sess24, "cfg3": cfg3, "cfg3_noise1": cfg3_noise1, "cfg3_24": cfg3_24}[_args[0]]()

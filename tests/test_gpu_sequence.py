@@ -976,6 +976,34 @@ def test_config3_at_full_length_against_the_reference_itself(nets_multi):
     assert core.stats()["bank_fwd"] >= T - 2                     # every frame but the last entered the bank
 
 
+def test_config3_first_24_frames_against_the_reference_and_its_own_spread(nets_multi):
+    """The clip of bench.py's default config-3 parity leg (480x854, k = 5, mem_freq = 1, T = 24): the HIP engine against the label map the
+    REFERENCE produced for exactly this clip (tests/golden/long_cfg3_24.npz), with the reference's OWN spread on this clip as the yardstick
+    (selfnoise row `cfg3_24`: 1 thread vs 8 threads - 255 px differ, worst object 5.0e-4 on the clip, worst (object, frame) 2.8e-3).
+    The bar: every object holds 1e-3 on the clip; every (object, frame) holds max(1e-3, 1.5 x the reference's worst frame, 2 px / union)."""
+    g = _long_golden("long_cfg3_24")
+    T, H, W, k, mf = (int(v) for v in g["shape"])
+    row = load_golden("selfnoise")["cfg3_24"][0]
+    img, msk = synth.synthetic_clip(T, H, W), synth.synthetic_mask(T, H, W, k)
+    m0 = torch.cat([1 - msk[:, 0].sum(0, keepdim=True).clamp(0, 1), msk[:, 0]], 0)
+    core = make_core(nets_multi)(img, k, mf)
+    a, b = core.interact(m0, 0, scribble=True), g["masks"]
+    px = int((a != b).sum())
+    clip = [1 - iou(a == o, b == o) for o in range(1, k + 1)]
+    over = []
+    for o in range(1, k + 1):
+        x, y = (a == o).reshape(T, -1), (b == o).reshape(T, -1)
+        u, n = (x | y).sum(1), (x & y).sum(1)
+        miss = np.where(u >= 64, 1 - n / np.maximum(u, 1), 0.0)
+        bound = np.array([frame_bound(row[4], v) for v in u])
+        over.append(float((miss / bound).max()))
+    print(f"HIP vs REFERENCE config 3, 24 frames: {px} of {a.size} px differ (reference vs itself: {int(row[3])}); clip 1-IoU per object {['%.2e' % v for v in clip]} "
+          f"(reference vs itself, worst object: {row[0]:.2e}); worst (object, frame) measured / bound per object {['%.2f' % v for v in over]}")
+    assert max(clip) <= 1e-3, clip
+    assert max(over) <= 1.0, over
+    assert px <= 4 * row[3], (px, row[3])
+
+
 _POOL_SCRIPT = r"""
 import sys, torch
 sys.path.insert(0, %r)

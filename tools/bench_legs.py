@@ -297,8 +297,11 @@ def config3_parity(prop, fuse, psd, fsd, T, H, W, k):
     # the reference against itself under the multi-object recipe at 480p; for (nearly) full-length clips also its own drift over 103
     # propagated frames of the config-3 clip (selfnoise row "cfg3full": 4 vs 8 intra-op threads, oracle/gen_golden.py NOISE_ONLY_CASES)
     tags = ["seq480k5", "seq480k3", "seq640k3"]
-    if T >= 52 and "cfg3full" in np.load(os.path.join(ROOT, "tests", "golden", "selfnoise.npz")).files:
+    sn_files = np.load(os.path.join(ROOT, "tests", "golden", "selfnoise.npz")).files
+    if T >= 52 and "cfg3full" in sn_files:
         tags.append("cfg3full")
+    if (T, H, W, k) == (24, 480, 854, 5) and "cfg3_24" in sn_files:
+        tags.append("cfg3_24")          # the reference against itself (1 vs 8 threads) on exactly THIS clip (oracle/gen_golden_long.py cfg3_24)
     noise = ref_self_noise(*tags)
     ious, fmin, fwhere, per_obj, ok = [], 1.0, None, [], True
     for o in range(1, k + 1):
@@ -325,25 +328,35 @@ def config3_parity(prop, fuse, psd, fsd, T, H, W, k):
     # ... and against the REFERENCE itself where its answer is on the box: tests/golden/long_cfg3.npz holds the label map the reference produced for
     # all 104 frames of the FULL-LENGTH workload (oracle/gen_golden_long.py).  The synthetic clip depends on its length, so the engine runs the first
     # T frames of the 104-frame clip once more (a forward sweep is causal: the first T frames of the reference's answer are its answer to that clip)
+    def against(gm, a_masks, what):
+        rows = []
+        for o in range(1, k + 1):
+            a_, b_ = a_masks == o, gm == o
+            fu, fi = (a_ | b_).reshape(T, -1).sum(1), (a_ & b_).reshape(T, -1).sum(1)
+            fiou = np.where(fu >= 64, fi / np.maximum(fu, 1), 1.0)
+            rows.append(dict(object=o, clip_miss=1 - float(fi.sum() / max(fu.sum(), 1)), worst_frame=int(fiou.argmin()), worst_frame_miss=float(1 - fiou.min())))
+        return dict(what=what, mask_pixels_differing=int((a_masks != gm).sum()), mask_pixels_total=int(gm.size), per_object=rows)
+
+    exact = os.path.join(ROOT, "tests", "golden", f"long_cfg3_{T}.npz")
     gpath = os.path.join(ROOT, "tests", "golden", "long_cfg3.npz")
-    if os.path.exists(gpath):
+    if os.path.exists(exact) and tuple(int(v) for v in np.load(exact)["shape"][:4]) == (T, H, W, k):
+        gm = np.load(exact)["masks"]
+        out["vs_reference_golden"] = against(gm, got, f"the HIP masks of this leg against the label map the REFERENCE itself produced for this very clip (tests/golden/long_cfg3_{T}.npz, 8 threads)")
+        out["vs_reference_golden"]["cpu_oracle"] = against(gm, ref, "the CPU oracle's masks of this leg against the same label map")
+        sn = np.load(os.path.join(ROOT, "tests", "golden", "selfnoise.npz"))
+        if f"cfg3_{T}" in sn.files:
+            r_ = sn[f"cfg3_{T}"][0]
+            out["vs_reference_golden"]["reference_vs_itself"] = dict(what="the reference at 1 vs 8 threads on this clip", clip_miss_worst_object=float(r_[0]),
+                                                                     differing_px=float(r_[3]), worst_frame_miss=float(r_[4]))
+    elif os.path.exists(gpath):
         gl = np.load(gpath)
         Tg = int(gl["shape"][0])
         if tuple(int(v) for v in gl["shape"][1:4]) == (H, W, k) and T <= Tg:
             img_g, gt_g = synth.synthetic_clip(Tg, H, W)[:, :T].contiguous(), synth.synthetic_mask(Tg, H, W, k)
             mg = torch.cat([1 - gt_g[:, 0].sum(0, keepdim=True).clamp(0, 1), gt_g[:, 0]], 0)
             got_g = InferenceCore(prop, fuse, img_g.cuda(), k, mem_freq=1).interact(mg, 0, scribble=True)
-            rm = gl["masks"][:T]
-            rows = []
-            for o in range(1, k + 1):
-                a_, b_ = got_g == o, rm == o
-                fu, fi = (a_ | b_).reshape(T, -1).sum(1), (a_ & b_).reshape(T, -1).sum(1)
-                fiou = np.where(fu >= 64, fi / np.maximum(fu, 1), 1.0)
-                rows.append(dict(object=o, clip_miss=1 - float(fi.sum() / max(fu.sum(), 1)), worst_frame=int(fiou.argmin()), worst_frame_miss=float(1 - fiou.min())))
-            out["vs_reference_golden"] = dict(what=f"HIP engine on the first {T} frames of the {Tg}-frame config-3 clip against the same frames of tests/golden/long_cfg3.npz: the label map of "
-                                                   "the REFERENCE itself (8 threads)", mask_pixels_differing=int((got_g != rm).sum()), mask_pixels_total=int(rm.size), per_object=rows,
-                                              reference_vs_itself_full_length="1 vs 8 threads, T=104: 824 of 42.6 M px, clip miss per object 1.8e-4 .. 4.6e-4; HIP engine at T=104: 2333 px, "
-                                                                              "objects 1-2 <= 4.4e-4, objects 3-5 1.0-1.8e-3 (profiles/r06_bn_unfolded_ab.txt)")
+            out["vs_reference_golden"] = against(gl["masks"][:T], got_g, f"HIP engine on the first {T} frames of the {Tg}-frame config-3 clip against the same frames of "
+                                                 "tests/golden/long_cfg3.npz: the label map of the REFERENCE itself (8 threads)")
     del core
     torch.cuda.empty_cache()
     return out
