@@ -145,20 +145,21 @@ void upsample2x_add_launch(const float *x, const float *skip, float *u, int B, i
                        skip, u, B, h, w, C, skip_bs, skip_bmod);
 }
 
-// aggregate_wbg (aggregate.py:22-37) on up to 8 objects: odds / sum(odds) after clamping
-#define STCN_MAX_OBJ 8
+// aggregate_wbg (aggregate.py:22-37): odds / sum(odds) after clamping.  MAXOBJ = 8 (every caller of the reference: k = 1, BASELINE config 3:
+// k = 5) or STCN_MAX_OBJECTS: the probabilities of a pixel stay in registers either way, the arithmetic and its order are the same.
+template <int MAXOBJ>
 __device__ __forceinline__ void aggregate_store(const float *p, int k, float *agg, long stride, long pix) {
     float bg = 1.f;
 #pragma unroll
-    for (int o = 0; o < STCN_MAX_OBJ; ++o)
+    for (int o = 0; o < MAXOBJ; ++o)
         if (o < k) bg *= (1.f - p[o]);
     const float lo = 1e-7f, hi = 1.f - 1e-7f;
-    float odds[STCN_MAX_OBJ + 1];
+    float odds[MAXOBJ + 1];
     float q = fminf(fmaxf(bg, lo), hi);
     odds[0] = q / (1.f - q);
     float tot = odds[0];
 #pragma unroll
-    for (int o = 0; o < STCN_MAX_OBJ; ++o) {
+    for (int o = 0; o < MAXOBJ; ++o) {
         if (o < k) {
             q = fminf(fmaxf(p[o], lo), hi);
             odds[o + 1] = q / (1.f - q);
@@ -167,11 +168,12 @@ __device__ __forceinline__ void aggregate_store(const float *p, int k, float *ag
     }
     agg[pix] = odds[0] / tot;
 #pragma unroll
-    for (int o = 0; o < STCN_MAX_OBJ; ++o)
+    for (int o = 0; o < MAXOBJ; ++o)
         if (o < k) agg[(o + 1) * stride + pix] = odds[o + 1] / tot;
 }
 
 // Decoder tail (prop_net.py:27-29,192) + aggregate: logit4 -> bilinear x4 -> sigmoid -> aggregate
+template <int MAXOBJ>
 __global__ void up4_sigmoid_aggregate_kernel(const float *__restrict__ logit4, int k, int h4, int w4,
                                              float *__restrict__ agg, long stride, long obj_stride, long logit_gs, long agg_gs) {
     const int H = 4 * h4, W = 4 * w4;
@@ -184,9 +186,9 @@ __global__ void up4_sigmoid_aggregate_kernel(const float *__restrict__ logit4, i
     bil(oy, 0.25f, h4, y0, y1, fy);
     bil(ox, 0.25f, w4, x0, x1, fx);
     const float w00 = (1.f - fy) * (1.f - fx), w01 = (1.f - fy) * fx, w10 = fy * (1.f - fx), w11 = fy * fx;
-    float p[STCN_MAX_OBJ];
+    float p[MAXOBJ];
 #pragma unroll
-    for (int o = 0; o < STCN_MAX_OBJ; ++o) {
+    for (int o = 0; o < MAXOBJ; ++o) {
         p[o] = 0.f;
         if (o < k) {
             const float *l = logit4 + (long)o * obj_stride;
@@ -195,27 +197,34 @@ __global__ void up4_sigmoid_aggregate_kernel(const float *__restrict__ logit4, i
             p[o] = sigmoidf_(v);
         }
     }
-    aggregate_store(p, k, agg, stride, i);
+    aggregate_store<MAXOBJ>(p, k, agg, stride, i);
 }
 void up4_sigmoid_aggregate_launch(const float *logit4, int k, int h4, int w4, float *agg, long agg_stride,
                                   hipStream_t s, long obj_stride, int G, long logit_gs, long agg_gs) {
-    hipLaunchKernelGGL(up4_sigmoid_aggregate_kernel, dim3(nblocks(16L * h4 * w4), G), dim3(256), 0, s, logit4, k, h4,
-                       w4, agg, agg_stride, obj_stride ? obj_stride : (long)h4 * w4, logit_gs, agg_gs);
+    const dim3 grid(nblocks(16L * h4 * w4), G);
+    const long os = obj_stride ? obj_stride : (long)h4 * w4;
+    if (k <= 8)
+        hipLaunchKernelGGL(up4_sigmoid_aggregate_kernel<8>, grid, dim3(256), 0, s, logit4, k, h4, w4, agg, agg_stride, os, logit_gs, agg_gs);
+    else
+        hipLaunchKernelGGL(up4_sigmoid_aggregate_kernel<STCN_MAX_OBJECTS>, grid, dim3(256), 0, s, logit4, k, h4, w4, agg, agg_stride, os, logit_gs, agg_gs);
 }
 
 // fusion tail (inference_core.py:203-207): sigmoid(fuse_net(...)) per object -> aggregate
+template <int MAXOBJ>
 __global__ void sigmoid_aggregate_kernel(const float *__restrict__ logit, int k, long npix,
                                          float *__restrict__ agg, long stride) {
     const long i = blockIdx.x * 256L + threadIdx.x;
     if (i >= npix) return;
-    float p[STCN_MAX_OBJ];
+    float p[MAXOBJ];
 #pragma unroll
-    for (int o = 0; o < STCN_MAX_OBJ; ++o) p[o] = o < k ? sigmoidf_(logit[o * npix + i]) : 0.f;
-    aggregate_store(p, k, agg, stride, i);
+    for (int o = 0; o < MAXOBJ; ++o) p[o] = o < k ? sigmoidf_(logit[o * npix + i]) : 0.f;
+    aggregate_store<MAXOBJ>(p, k, agg, stride, i);
 }
 void sigmoid_aggregate_launch(const float *logit, int k, long npix, float *agg, long agg_stride, hipStream_t s) {
-    hipLaunchKernelGGL(sigmoid_aggregate_kernel, dim3(nblocks(npix)), dim3(256), 0, s, logit, k, npix, agg,
-                       agg_stride);
+    if (k <= 8)
+        hipLaunchKernelGGL(sigmoid_aggregate_kernel<8>, dim3(nblocks(npix)), dim3(256), 0, s, logit, k, npix, agg, agg_stride);
+    else
+        hipLaunchKernelGGL(sigmoid_aggregate_kernel<STCN_MAX_OBJECTS>, dim3(nblocks(npix)), dim3(256), 0, s, logit, k, npix, agg, agg_stride);
 }
 
 // final masks (inference_core.py:247-248): argmax over the k+1 rows, first maximum wins

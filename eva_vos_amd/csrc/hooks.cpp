@@ -1,4 +1,5 @@
 // hooks.cpp - stage-level C-ABI entry points used by tests/ and bench.py (see include/stcn_hip.h).
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -164,7 +165,7 @@ int stcn_test_encode_key(const stcn_model *m, void *stream, const float *img, in
 
 int stcn_test_encode_value(const stcn_model *m, void *stream, const float *img, const float *f16, const float *masks, int k,
                            int nh, int nw, float *out) {
-    if (!m || !img || !f16 || !masks || !out || k < 1 || k > 8) { set_error("stcn_test_encode_value: bad arguments"); return STCN_E_INVALID; }
+    if (!m || !img || !f16 || !masks || !out || k < 1 || k > STCN_MAX_OBJECTS) { set_error("stcn_test_encode_value: bad arguments"); return STCN_E_INVALID; }
     hipStream_t s = (hipStream_t)stream;
     TmpWork t(nh, nw, k);
     RC(t.rc);
@@ -256,12 +257,12 @@ int stcn_test_decode(const stcn_model *m, void *stream, const float *readout, co
 
 int stcn_test_attention(void *stream, const float *mk, const float *qk, const float *pos, const float *neg, int kk, int nh,
                         int nw, float *attn) {
-    if (!mk || !qk || !pos || !neg || !attn || kk < 1 || kk > 9) { set_error("stcn_test_attention: bad arguments"); return STCN_E_INVALID; }
+    if (!mk || !qk || !pos || !neg || !attn || kk < 1 || kk > STCN_MAX_OBJECTS + 1) { set_error("stcn_test_attention: bad arguments"); return STCN_E_INVALID; }
     hipStream_t s = (hipStream_t)stream;
     const int h = nh / 16, w = nw / 16;
     DevBuf msq, pooled, amap, gm, cm, part;
-    RC(gm.alloc((size_t)256 * h * w)); RC(cm.alloc(h * w)); RC(part.alloc((size_t)16 * h * w * 19));
-    RC(msq.alloc(h * w + 64)); RC(pooled.alloc((size_t)20 * h * w)); RC(amap.alloc((size_t)kk * 2 * h * w));
+    RC(gm.alloc((size_t)256 * h * w)); RC(cm.alloc(h * w)); RC(part.alloc(attention_part_floats(kk, h * w)));
+    RC(msq.alloc(h * w + 64)); RC(pooled.alloc((size_t)std::max(20, attention_nchp(2 * kk)) * h * w)); RC(amap.alloc((size_t)kk * 2 * h * w));
     rowsumsq_launch(mk, h * w, 64, msq.p, s);
     HIPCHK(hipMemsetAsync(msq.p, 0, (size_t)(h * w + 64) * 4, s));
     rowsumsq_launch(mk, h * w, 64, msq.p, s);

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/stcn_hip.h"   // STCN_MAX_OBJECTS
+
 namespace stcn {
 
 // ---------------------------------------------------------------- division by a launch invariant
@@ -190,8 +192,10 @@ void allow_big_lds(const void *kernel, size_t lds);
 void memory_read_launch(const float *mk, const float *msq, const float *qk, int N, int Q,
                         const float *mv, long mv_os, int k, float *readout, long ro_os,
                         int32_t *topk_idx, float *topk_w, MemReadScratch scr, hipStream_t s);
-// fusion attention read: mk,qk [hw,64]; pos,neg [kk][16h*16w planes] -> attn [kk][2][nh*nw]; pooled: scratch of 20 * h * w floats
-struct AttnScratch { float *gmax, *cmax, *part; };   // [256][hw], [hw], [16][hw][19]
+// fusion attention read: mk,qk [hw,64]; pos,neg [kk][16h*16w planes] -> attn [kk][2][nh*nw]; pooled: scratch of attention_nchp(2 kk) * h * w floats
+struct AttnScratch { float *gmax, *cmax, *part; };   // [256][hw], [hw], attention_part_floats(kk, hw) ([16][hw][19] up to 8 objects)
+int attention_nchp(int nch);                          // channels 2 kk padded to the widths the pass kernel is instantiated for
+size_t attention_part_floats(int kk, int hw);
 // pos == nullptr: `pooled` already holds attention_pool_launch's output for this interaction
 void attention_pool_launch(const float *pos, const float *neg, int kk, int h, int w, float *pooled, hipStream_t s);
 void attention_read_launch(const float *mk, const float *msq, const float *qk, const float *pos,

@@ -704,17 +704,19 @@ __global__ void area_pool16_kernel(const float *__restrict__ pos, const float *_
     pooled[(long)cell * nchp + c] = acc * (1.f / 256.f);
 }
 
-// channels of the attention read padded to the instantiated widths (2 (k + 1) = 4 ... 18)
-static int attention_nchp(int nch) { return nch <= 4 ? 4 : (nch <= 8 ? 8 : (nch <= 12 ? 12 : 20)); }
-
-#define STCN_ATT_MAXCH 18   // (k+1)*2 with k <= 8
+// channels of the attention read padded to the instantiated widths (2 (k + 1) = 4 ... 18); with more than 8 objects to a multiple of 20:
+// the pass kernel then runs once per slice of 20 channels (same column maxima, same row order: every channel's sum is what one wide pass gives)
+int attention_nchp(int nch) { return nch <= 4 ? 4 : (nch <= 8 ? 8 : (nch <= 12 ? 12 : 20 * ((nch + 19) / 20))); }
+// floats per (chunk, query) of the partial sums: the softmax denominator + one per channel (19 up to 8 objects, as sized since round 2)
+static int attention_part_stride(int nch) { return 1 + (nch <= 18 ? 18 : nch); }
+size_t attention_part_floats(int kk, int hw) { return (size_t)MAXCHUNK * hw * attention_part_stride(2 * kk); }
 // pass 2 of the attention read: per (query block, row chunk) partial sums of e = exp(S - cmax[q]), cmax = exact column maximum:
 //   part[chunk][q][0] = sum_m e,  part[chunk][q][1 + c] = sum_m e * pooled[c][m]
 template <int WAVES, int NCHP>
 __global__ __launch_bounds__(64 * WAVES) void attention_pass_kernel(
     const float *__restrict__ mk, const float *__restrict__ msq, const float *__restrict__ qk, int N, int Q,
     int steps_per_chunk, const float *__restrict__ gmax, int G, const float *__restrict__ pooled, int nch,
-    float *__restrict__ part) {
+    float *__restrict__ part, int prow, int pstr, int ch0) {      // pooled: first channel of this slice, row stride prow; nch: channels of this slice; part: [..][pstr], channel ch0 + c
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q0 = (blockIdx.x * WAVES + wave) * 16;
     if (q0 >= Q) return;
@@ -749,7 +751,7 @@ __global__ __launch_bounds__(64 * WAVES) void attention_pass_kernel(
             for (int j = 0; j < 4; ++j) {
                 const int rr = min(row0 + rb * 16 + 4 * g + j, N - 1);
 #pragma unroll
-                for (int c4 = 0; c4 < NCHP / 4; ++c4) d[j][c4] = *reinterpret_cast<const f32x4 *>(pooled + (long)rr * NCHP + 4 * c4);
+                for (int c4 = 0; c4 < NCHP / 4; ++c4) d[j][c4] = *reinterpret_cast<const f32x4 *>(pooled + (long)rr * prow + 4 * c4);
             }
         };
         pload(0, pl[0]);
@@ -774,23 +776,23 @@ __global__ __launch_bounds__(64 * WAVES) void attention_pass_kernel(
 #pragma unroll
     for (int c = 0; c < NCHP; ++c) { a[c] += __shfl_xor(a[c], 16); a[c] += __shfl_xor(a[c], 32); }
     if (g == 0 && q0 + col < Q) {
-        float *dst = part + ((long)chunk * Q + q0 + col) * (1 + STCN_ATT_MAXCH);
-        dst[0] = l;
+        float *dst = part + ((long)chunk * Q + q0 + col) * pstr;
+        if (ch0 == 0) dst[0] = l;
 #pragma unroll
         for (int c = 0; c < NCHP; ++c)
-            if (c < nch) dst[1 + c] = a[c];
+            if (c < nch) dst[1 + ch0 + c] = a[c];
     }
 }
 
-__global__ void attention_finalize_kernel(const float *__restrict__ part, int NC, int Q, int nch,
+__global__ void attention_finalize_kernel(const float *__restrict__ part, int NC, int Q, int nch, int pstr,
                                           float *__restrict__ amap) {
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= Q) return;
     float l = 0.f;
-    for (int ch = 0; ch < NC; ++ch) l += part[((long)ch * Q + q) * (1 + STCN_ATT_MAXCH)];
+    for (int ch = 0; ch < NC; ++ch) l += part[((long)ch * Q + q) * pstr];
     for (int c = 0; c < nch; ++c) {
         float acc = 0.f;
-        for (int ch = 0; ch < NC; ++ch) acc += part[((long)ch * Q + q) * (1 + STCN_ATT_MAXCH) + 1 + c];
+        for (int ch = 0; ch < NC; ++ch) acc += part[((long)ch * Q + q) * pstr + 1 + c];
         amap[(long)c * Q + q] = acc / l;
     }
 }
@@ -837,15 +839,18 @@ void attention_read_launch(const float *mk, const float *msq, const float *qk, c
     const int NCeff = (steps + spc - 1) / spc;
     const dim3 grid(qblocks, NCeff);
     hipLaunchKernelGGL((colmax_pass_kernel<WAVES>), grid, dim3(64 * WAVES), 0, s, mk, msq, qk, hw, hw, spc, scr.gmax);
-    switch (attention_nchp(nch)) {
-#define STCN_AP(N_) hipLaunchKernelGGL((attention_pass_kernel<WAVES, N_>), grid, dim3(64 * WAVES), 0, s, mk, msq, qk, hw, hw, spc, scr.gmax, NCeff * NGRP, pooled, nch, scr.part)
-        case 4: STCN_AP(4); break;
-        case 8: STCN_AP(8); break;
-        case 12: STCN_AP(12); break;
-        default: STCN_AP(20); break;
+    const int nchp = attention_nchp(nch), pstr = attention_part_stride(nch);
+    switch (nchp) {
+#define STCN_AP(N_, C0_, NCH_) hipLaunchKernelGGL((attention_pass_kernel<WAVES, N_>), grid, dim3(64 * WAVES), 0, s, mk, msq, qk, hw, hw, spc, scr.gmax, NCeff * NGRP, pooled + (C0_), NCH_, scr.part, nchp, pstr, C0_)
+        case 4: STCN_AP(4, 0, nch); break;
+        case 8: STCN_AP(8, 0, nch); break;
+        case 12: STCN_AP(12, 0, nch); break;
+        default:
+            for (int c0 = 0; c0 < nch; c0 += 20) STCN_AP(20, c0, nch - c0 < 20 ? nch - c0 : 20);
+            break;
 #undef STCN_AP
     }
-    hipLaunchKernelGGL(attention_finalize_kernel, dim3((hw + 255) / 256), dim3(256), 0, s, scr.part, NCeff, hw, nch,
+    hipLaunchKernelGGL(attention_finalize_kernel, dim3((hw + 255) / 256), dim3(256), 0, s, scr.part, NCeff, hw, nch, pstr,
                        amap);
     const long tot = (long)nch * 256 * hw;
     hipLaunchKernelGGL(bilinear_up16_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, amap, nch, h, w,

@@ -32,6 +32,10 @@ extern "C" {
 #define STCN_E_HIP        -3   /* HIP runtime error */
 #define STCN_E_STATE      -4   /* call not valid in the current engine state */
 
+/* Objects per engine (`num_objects` of InferenceCore.__init__, mivos/inference_core.py:34): the reference class has no limit (its own
+ * pipelines pass 1: datasets/annotation_dataset.py:55-67); this library is built and tested for 1 .. STCN_MAX_OBJECTS. */
+#define STCN_MAX_OBJECTS  32
+
 typedef struct stcn_model  stcn_model;   /* folded + repacked weights, read-only, shareable */
 typedef struct stcn_engine stcn_engine;  /* per-video state */
 

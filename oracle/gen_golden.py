@@ -261,6 +261,11 @@ SEQ_CASES = {
     # ground truth (interactions/mask.py:33-36 charges SKIP_SECONDS for it; interactions/eval.py NO_OBJECT) - interact(0), then interact(5) with
     # zeros (certain memory gets a value encoded from an empty mask, fusion towards it), then interact(2) with a real mask again
     "seqE": dict(H=128, W=160, k=1, T=9, mem_freq=3, script=[(0, 0), (5, 5), (2, 2)], empty=(1,)),
+    # MORE THAN 8 OBJECTS (round 6: the engine's limit went from 8 to STCN_MAX_OBJECTS = 32; the reference class has none): 10 objects (the
+    # most a DAVIS-2017 video holds) and 16, a propagation and a FUSED second interaction each (attention read over 22 / 34 channels, the
+    # aggregation over 11 / 17 rows), under the multi-object recipe
+    "seqK10": dict(H=192, W=160, k=10, T=7, mem_freq=2, script=[(0, 0), (4, 4)], seed=2, prob_stride=4),
+    "seqK16": dict(H=256, W=192, k=16, T=6, mem_freq=3, script=[(0, 0), (4, 4)], seed=2, prob_stride=4),
 }
 # BASELINE resolution end to end from the reference: 6 frames 480x854 (padded to 864), interact(0) then interact(4) with
 # fusion on frames 1..3; packed masks + every 4th prob sample as fp16 (< 1 MB).  ~1.6 s per frame and network pass here.

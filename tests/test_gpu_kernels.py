@@ -436,8 +436,12 @@ def test_near_tie_queries_are_the_only_ones_that_differ():
     assert (gro - own).abs().max() / own.abs().max() < 2e-5
 
 
-def test_attention_read_matches_oracle():
-    h, w, kk = 8, 10, 4
+@pytest.mark.parametrize("kk", [2, 4, 6, 9, 10, 11, 17, 21, 33])
+def test_attention_read_matches_oracle(kk):
+    """kk = mask rows (objects + background): 2 kk channels.  Up to 9 rows run in one pass of the instantiated widths (4 / 8 / 12 / 20
+    channels); beyond (more than 8 objects, round 6) the pass runs per slice of 20 channels: 10 -> one full slice, 11 -> 20 + 2, 17 -> 20 + 14,
+    21 -> 20 + 20 + 2, 33 (STCN_MAX_OBJECTS + 1) -> 20 + 20 + 20 + 6."""
+    h, w = 8, 10
     g = torch.Generator().manual_seed(11)
     mk, qk = torch.randn(h * w, 64, generator=g), torch.randn(h * w, 64, generator=g)
     pos = torch.rand(kk, 1, 16 * h, 16 * w, generator=g)

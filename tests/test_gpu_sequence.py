@@ -68,14 +68,14 @@ def nets_of(g, tag, nets, weights):
     return (p.eval(), f.eval()), w
 
 
-@pytest.mark.parametrize("tag", ["seqA", "seqA1", "seqB", "seqC", "seqD", "seqE", "seq480", "seq480L", "seq480k5", "seq480k3", "seq480P", "seq640k3"])
+@pytest.mark.parametrize("tag", ["seqA", "seqA1", "seqB", "seqC", "seqD", "seqE", "seq480", "seq480L", "seq480k5", "seq480k3", "seq480P", "seq640k3", "seqK10", "seqK16"])
 def test_sequences_match_reference_goldens(tag, nets, weights):
     """seqA1 = the seqA script under weight recipe seed 1, seq480k5 = BASELINE config 3's shape (480x854, 5 objects, every
     frame enters the bank), seq480k3 = three objects at 480p with a second, FUSED interaction (both under the multi-object recipe,
     all pixels), seq480P = a PORTRAIT clip with an odd long side (853x480 -> pad (0,0,5,6), 54 x 30 keys: what scripts/resize.py makes of a
     portrait MOSE video), seq640k3 = 4:3 (480x640), three objects, seqE = a round annotated with an EMPTY mask (the object has left the frame:
     the reference's loops annotate such a frame with its all-zero ground truth) - all held to the SAME statements and tolerances as the seed-0 /
-    single-object fixtures."""
+    single-object fixtures.  seqK10 / seqK16 = 10 and 16 objects (beyond the 8 of rounds 1-5), a propagation and a fused second interaction."""
     g = load_golden(tag)
     nets, weights = nets_of(g, tag, nets, weights)
     outs = run_sequence(make_core(nets), tag, g)
@@ -646,8 +646,48 @@ def test_eight_objects_is_the_engine_maximum_and_works(nets):
     assert np.array_equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert (outs[0][1][:, 1:].sum(0) - 1).abs().max() < 1e-5
     assert set(np.unique(outs[0][0])) <= set(range(k + 1))
-    with pytest.raises(RuntimeError, match="1<=k<=8"):
-        make_core(nets)(img, 9, 3)
+    with pytest.raises(RuntimeError, match="1<=k<=32"):        # include/stcn_hip.h: STCN_MAX_OBJECTS (the reference class has no limit)
+        make_core(nets)(img, 33, 3)
+
+
+def test_thirty_two_objects_against_the_oracle(nets_multi, weights_multi):
+    """STCN_MAX_OBJECTS = 32 objects in one engine (the reference class has no limit; rounds 1-5 stopped at 8): a propagation and a FUSED
+    second interaction through the scribble path on a 160x192 clip against the CPU oracle - probabilities of all 33 rows on every
+    pixel, the label map, and the rows of a frame summing to one.  (seqK10 / seqK16 hold the same against the REFERENCE's own output.)"""
+    T, H, W, k = 5, 160, 192, 32
+    img, msk = synth.synthetic_clip(T, H, W, seed=3), synth.synthetic_mask(T, H, W, k, seed=4)
+    core = make_core(nets_multi)(img, k, 2)
+    orc = O.OracleCore(weights_multi[0], weights_multi[1], img, k, mem_freq=2)
+    for r, f in enumerate((0, 3)):
+        m = torch.cat([1 - msk[:, f].sum(0, keepdim=True).clamp(0, 1), msk[:, f]], 0)
+        a, b = core.interact(m, f, scribble=True), orc.interact(m.clone(), f, scribble=True)
+        d = (core.prob.cpu() - orc.prob).abs()
+        diff = int((a != b).sum())
+        print(f"k = 32 round {r}: max |dprob| {float(d.max()):.1e}, p99.9 {float(torch.quantile(d.flatten()[::3], 0.999)):.1e}, {diff} of {a.size} labels differ; "
+              f"labels present {len(np.unique(b))}")
+        assert float(torch.quantile(d.flatten()[::3], 0.999)) < 1e-3 and diff <= 1e-3 * a.size, (r, float(d.max()), diff)
+        free = [t for t in range(T) if t not in (0, 3)]             # (an interacted frame holds the given mask rows, which overlap)
+        assert (core.prob[:, free].sum(0) - 1).abs().max() < 1e-5
+    s = core.stats()
+    assert s["fused"] > 0 and s["value_enc"] >= 3
+
+
+@pytest.mark.parametrize("k", [10, 32])
+def test_many_objects_at_480p_against_the_oracle(k, nets_multi, weights_multi):
+    """The BASELINE frame size with more than 8 objects (10 = the most a DAVIS-2017 video holds; 32 = STCN_MAX_OBJECTS): workspaces, Winograd
+    chunking and every batched launch at objects x 480x864.  Three frames, every frame in the bank, HIP engine against the CPU oracle."""
+    T, H, W = 3, 480, 854
+    img, msk = synth.synthetic_clip(T, H, W), synth.synthetic_mask(T, H, W, k)
+    m0 = torch.cat([1 - msk[:, 0].sum(0, keepdim=True).clamp(0, 1), msk[:, 0]], 0)
+    core = make_core(nets_multi)(img, k, 1)
+    orc = O.OracleCore(weights_multi[0], weights_multi[1], img, k, mem_freq=1)
+    a, b = core.interact(m0, 0, scribble=True), orc.interact(m0.clone(), 0, scribble=True)
+    d = (core.prob.cpu() - orc.prob).abs()
+    q = float(torch.quantile(d.flatten()[::max(7, d.numel() // 8000000 + 1)], 0.999))
+    diff = int((a != b).sum())
+    print(f"k = {k} at 480p: max |dprob| {float(d.max()):.1e}, p99.9 {q:.1e}, {diff} of {a.size} labels differ, labels present {len(np.unique(b))}")
+    assert q < 1e-3 and diff <= 1e-3 * a.size, (k, q, diff)
+    assert (core.prob[:, 1:].sum(0) - 1).abs().max() < 1e-5
 
 
 def test_a_failing_interaction_leaves_a_defined_state(nets):

@@ -206,7 +206,7 @@ def check_sequence_against_golden(outs, tag, g, prob_atol, min_iou=1 - 1e-3, tie
         assert q999 <= tail, (tag, r, q999, tail)
 
 
-@pytest.mark.parametrize("tag", ["seqA", "seqA1", "seqB", "seqC", "seqD", "seqE", "seq480", "seq480L", "seq480k5", "seq480k3", "seq480P", "seq640k3"])
+@pytest.mark.parametrize("tag", ["seqA", "seqA1", "seqB", "seqC", "seqD", "seqE", "seq480", "seq480L", "seq480k5", "seq480k3", "seq480P", "seq640k3", "seqK10", "seqK16"])
 def test_sequence_matches_reference(tag, weights):
     g = load_golden(tag)
     weights = weights_of(g, tag, weights)
