@@ -633,9 +633,9 @@ def test_multi_object_decode_groups_equal_the_frame_by_frame_path(nets_multi, mo
     assert float(torch.quantile(d.flatten()[::3].float(), 0.999)) < 1e-3, float(d.max())
 
 
-def test_eight_objects_is_the_engine_maximum_and_works(nets):
-    """k = 8 (the engine's stated maximum; decode groups shrink to 2 frames so that objects x frames <= 16): probabilities
-    are a distribution, every object keeps pixels, a repeat is bit-identical; k = 9 is refused with a message."""
+def test_eight_objects_work_and_the_stated_maximum_is_enforced(nets):
+    """k = 8 (the most the 8-object instantiation of the aggregation kernels holds; decode groups shrink to 2 frames so that objects x frames
+    <= 16): probabilities are a distribution, every object keeps pixels, a repeat is bit-identical; k = STCN_MAX_OBJECTS + 1 = 33 is refused with a message."""
     T, H, W, k = 6, 128, 160, 8
     img, msk = synth.synthetic_clip(T, H, W, seed=11), synth.synthetic_mask(T, H, W, k, seed=12)
     m0 = torch.cat([1 - msk[:, 0].sum(0, keepdim=True).clamp(0, 1), msk[:, 0]], 0)
